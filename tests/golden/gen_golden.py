@@ -1,0 +1,549 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the build container (needs the reference checkout).
+
+It imports the reference's quantizer modules on CPU, feeds them the seeded synthetic inputs of
+``miq.synth`` and stores inputs (small cases), outputs, intermediates and gradients as plain tensor
+dictionaries under tests/golden/*.pt (loadable with ``torch.load(weights_only=True)``).  The
+fixtures, not the reference, travel to the GPU box.
+
+Harness-side shims (none of them touches the arithmetic):
+  * ``termcolor`` (absent package, imported by the reference's logger) is replaced by a pass-through.
+  * ``MixAffineQuantizer.model_size_loss`` hard-codes ``.to("cuda")``; the generator maps that
+    device string to "cpu" for the duration of the call.
+
+Usage:  python tests/golden/gen_golden.py [--ref /root/reference]
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, "llm-quantization_amd"))
+
+from miq import synth  # noqa: E402
+
+F32, F16 = torch.float32, torch.float16
+DT = {"f32": F32, "f16": F16}
+
+
+def import_reference(ref_root):
+    sys.path.insert(0, ref_root)
+    sys.modules.setdefault("termcolor", types.SimpleNamespace(colored=lambda s, *a, **k: s))
+    mods = types.SimpleNamespace()
+    from quantize import quantizer, quantizer_exp, quantizer_exp_v2, quantizer_mix, quantizer_mix_v2
+    from quantize import reorder_utils, int_linear, int_matmul, omni_norm
+    mods.uni = quantizer
+    mods.exp1 = quantizer_exp
+    mods.exp2 = quantizer_exp_v2
+    mods.mix = quantizer_mix
+    mods.mix2 = quantizer_mix_v2
+    mods.reorder = reorder_utils
+    mods.int_linear = int_linear
+    mods.int_matmul = int_matmul
+    mods.omni_norm = omni_norm
+    return mods
+
+
+@contextlib.contextmanager
+def cuda_means_cpu():
+    orig = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple("cpu" if (isinstance(v, str) and v.startswith("cuda")) else v for v in a)
+        return orig(self, *a, **k)
+
+    torch.Tensor.to = to
+    try:
+        yield
+    finally:
+        torch.Tensor.to = orig
+
+
+def set_lwc(q, up, low):
+    with torch.no_grad():
+        q.upbound_factor.copy_(up)
+        q.lowbound_factor.copy_(low)
+
+
+def sample_rows(t, rows):
+    return t[rows].clone()
+
+
+def pack_big(d, name, t, rows):
+    """For large tensors store a content hash plus a few sampled rows."""
+    d[name + "_sha"] = synth.sha(t)
+    d[name + "_rows"] = sample_rows(t.detach(), rows)
+
+
+def weight_case_inputs(shape, dtype, edge, lwc, groups, seed):
+    if edge:
+        x = synth.weight_with_edge_rows(shape[0], shape[1], seed, dtype)
+    else:
+        x = synth.weight(shape[0], shape[1], seed, dtype)
+    up = low = None
+    if lwc:
+        up, low = synth.lwc_factors(groups, seed + 1, dtype)
+    w = synth.grad_like(x, seed + 2)
+    return x, up, low, w
+
+
+def n_groups(shape, group):
+    if not group:
+        return shape[0]
+    return shape[0] * int(np.ceil(shape[1] / group))
+
+
+def run_backward(out, w, x, params):
+    loss = (out.float() * w.float()).sum() if out.dtype == F16 else (out * w).sum()
+    # fp16: the reference trains by multiplying in the tensor dtype; we keep the loss in fp32 so
+    # that the only fp16 ops on the tape are the quantizer's own.
+    grads = torch.autograd.grad(loss, [x] + [p for p in params if p is not None], allow_unused=True)
+    return grads
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_uniform(ref):
+    cases = {}
+    Q = ref.uni.UniformAffineQuantizer
+
+    def one(name, shape, dt, bits, sym, lwc, group=None, edge=False, seed=2, big=False):
+        dtype = DT[dt]
+        x, up, low, w = weight_case_inputs(shape, dtype, edge, lwc, n_groups(shape, group), seed)
+        q = Q(n_bits=bits, symmetric=sym, per_channel_axes=[0], metric="minmax", dynamic=True,
+              dynamic_method="per_channel", group_size=group, shape=shape, lwc=lwc)
+        if dtype == F16:
+            q = q.half()
+        if lwc:
+            set_lwc(q, up, low)
+        xg = x.clone().requires_grad_(True)
+        out = q(xg)
+        params = [q.upbound_factor, q.lowbound_factor] if lwc else []
+        grads = run_backward(out, w, xg, params)
+        scale, rzp = q.scale.detach(), q.round_zero_point.detach()
+        # intermediate integer codes, by the reference's own op sequence (quantizer.py:100-112)
+        with torch.no_grad():
+            xr = x
+            if q.deficiency > 0:
+                xr = torch.cat((xr, torch.zeros((x.shape[0], q.deficiency), dtype=dtype)), dim=1)
+            if group:
+                xr = xr.reshape(-1, group)
+            qv = xr / scale
+            codes = ((qv.round() - qv) + qv).add(rzp).clamp(0, 2 ** bits - 1)  # round_ste: inf -> nan
+            deq = codes.sub(rzp).mul(scale)
+            if group:
+                deq = deq.reshape(shape[0], -1)
+                codes = codes.reshape(shape[0], -1)
+            if q.deficiency > 0:
+                deq = deq[:, :-q.deficiency]
+                codes = codes[:, :-q.deficiency]
+            assert torch.equal(torch.nan_to_num(deq, nan=123.0), torch.nan_to_num(out.detach(), nan=123.0)), name
+        d = {"meta": {"shape": list(shape), "dtype": dt, "n_bits": bits, "symmetric": sym, "lwc": lwc,
+                      "group_size": group or 0, "edge": edge, "seed": seed, "big": big},
+             "scale": scale.clone(), "rzp": rzp.clone(), "x_sha": synth.sha(x)}
+        if lwc:
+            d["d_up"], d["d_low"] = grads[1].clone(), grads[2].clone()
+        if big:
+            rows = [0, 1, shape[0] // 2, shape[0] - 1]
+            d["rows"] = rows
+            pack_big(d, "out", out, rows)
+            pack_big(d, "codes", codes.to(torch.uint8), rows)
+            pack_big(d, "dx", grads[0], rows)
+        else:
+            d["out"] = out.detach().clone()
+            d["codes"] = torch.nan_to_num(codes, nan=0.0).to(torch.int32)
+            d["dx"] = grads[0].clone()
+        cases[name] = d
+
+    for dt in ("f32", "f16"):
+        for bits in (2, 3, 4, 6, 8):
+            for sym in (False, True):
+                for lwc in (False, True):
+                    one(f"u_{dt}_b{bits}_{'sym' if sym else 'asym'}_{'lwc' if lwc else 'raw'}",
+                        (64, 96), dt, bits, sym, lwc)
+        for bits in (3, 4):
+            for sym in (False, True):
+                one(f"u_{dt}_b{bits}_{'sym' if sym else 'asym'}_lwc_edge", (12, 64), dt, bits, sym, True, edge=True)
+                one(f"u_{dt}_b{bits}_{'sym' if sym else 'asym'}_raw_edge", (12, 64), dt, bits, sym, False, edge=True)
+        for group in (128, 64):
+            for sym in (False, True):
+                one(f"u_{dt}_b4_{'sym' if sym else 'asym'}_lwc_g{group}", (32, 256), dt, 4, sym, True, group=group)
+        one(f"u_{dt}_b4_sym_lwc_g64_deficient", (32, 200), dt, 4, True, True, group=64)
+        one(f"u_{dt}_b3_sym_raw_g128_deficient", (16, 328), dt, 3, True, False, group=128)
+    # odd row lengths (scalar tail paths in the kernels)
+    one("u_f32_b4_asym_lwc_odd", (33, 77), "f32", 4, False, True)
+    one("u_f16_b4_asym_lwc_odd", (33, 77), "f16", 4, False, True)
+    # OPT-125m shapes (config 0), stored as hashes + sampled rows
+    one("u_f32_b3_asym_lwc_768x768", (768, 768), "f32", 3, False, True, big=True)
+    one("u_f32_b3_asym_lwc_3072x768", (3072, 768), "f32", 3, False, True, big=True)
+    one("u_f32_b3_asym_lwc_768x3072", (768, 3072), "f32", 3, False, True, big=True)
+    one("u_f16_b4_asym_lwc_768x768", (768, 768), "f16", 4, False, True, big=True)
+    one("u_f32_b4_sym_lwc_g128_768x3072", (768, 3072), "f32", 4, True, True, group=128, big=True)
+    return cases
+
+
+def gen_mix2(ref):
+    cases = {}
+    Q = ref.mix2.Mix2AffineQuantizer
+
+    def one(name, shape, sym, lwc, edge=False, seed=12):
+        x, up, low, w = weight_case_inputs(shape, F32, edge, lwc, shape[0], seed)
+        bits = synth.mix2_bits(shape[0], seed + 3)
+        q = Q(target_bit=3, symmetric=sym, per_channel_axes=[0], metric="minmax", dynamic=True,
+              dynamic_method="per_channel", group_size=None, shape=shape, mix2_nbits=bits, lwc=lwc)
+        if lwc:
+            set_lwc(q, up, low)
+        xg = x.clone().requires_grad_(True)
+        out = q(xg)
+        params = [q.upbound_factor, q.lowbound_factor] if lwc else []
+        grads = run_backward(out, w, xg, params)
+        d = {"meta": {"shape": list(shape), "dtype": "f32", "symmetric": sym, "lwc": lwc, "edge": edge, "seed": seed},
+             "bits": bits.clone(), "out": out.detach().clone(), "dx": grads[0].clone(), "x_sha": synth.sha(x)}
+        if lwc:
+            d["d_up"], d["d_low"] = grads[1].clone(), grads[2].clone()
+        cases[name] = d
+
+    for sym in (False, True):
+        for lwc in (False, True):
+            one(f"m2_{'sym' if sym else 'asym'}_{'lwc' if lwc else 'raw'}", (64, 96), sym, lwc)
+    one("m2_asym_lwc_edge", (20, 64), False, True, edge=True)
+    return cases
+
+
+def gen_exp1(ref):
+    cases = {}
+    Q = ref.exp1.ExpAffineQuantizer
+
+    def one(name, shape, dt, bits, sym, lwc, edge=False, seed=21):
+        dtype = DT[dt]
+        x, up, low, w = weight_case_inputs(shape, dtype, edge, lwc, shape[0], seed)
+        q = Q(n_bits=bits, symmetric=sym, per_channel_axes=[0], metric="minmax", dynamic=True,
+              dynamic_method="per_channel", group_size=None, shape=shape, lwc=lwc)
+        if dtype == F16:
+            q = q.half()
+        if lwc:
+            set_lwc(q, up, low)
+        xg = x.clone().requires_grad_(True)
+        out = q(xg)
+        params = [q.upbound_factor, q.lowbound_factor] if lwc else []
+        grads = run_backward(out, w, xg, params)
+        d = {"meta": {"shape": list(shape), "dtype": dt, "n_bits": bits, "symmetric": sym, "lwc": lwc,
+                      "edge": edge, "seed": seed},
+             "out": out.detach().clone(), "scale": q.scale.detach().clone(), "dx": grads[0].clone(),
+             "x_sha": synth.sha(x)}
+        if q.zero_point is not None:
+            d["mid"] = q.zero_point.detach().clone()
+        if lwc:
+            d["d_up"], d["d_low"] = grads[1].clone(), grads[2].clone()
+        cases[name] = d
+
+    for bits in (2, 3, 4):
+        for sym in (True, False):
+            for lwc in (False, True):
+                one(f"e1_f32_b{bits}_{'sym' if sym else 'asym'}_{'lwc' if lwc else 'raw'}", (64, 96), "f32", bits, sym, lwc)
+    one("e1_f32_b3_sym_lwc_edge", (12, 64), "f32", 3, True, True, edge=True)
+    one("e1_f16_b3_sym_lwc", (64, 96), "f16", 3, True, True)
+    return cases
+
+
+def gen_exp2(ref):
+    cases = {}
+    Q = ref.exp2.ExpAffineQuantizer
+
+    def one(name, shape, dt, bits, lwc, edge=False, seed=31, big=False):
+        dtype = DT[dt]
+        x, up, low, w = weight_case_inputs(shape, dtype, edge, lwc, shape[0], seed)
+        q = Q(n_bits=bits, symmetric=True, per_channel_axes=[0], metric="minmax", dynamic=True,
+              dynamic_method="per_channel", group_size=None, shape=shape, lwc=lwc)
+        if dtype == F16:
+            q = q.half()
+        if lwc:
+            set_lwc(q, up, low)
+        xg = x.clone().requires_grad_(True)
+        out = q(xg)
+        params = [q.upbound_factor, q.lowbound_factor] if lwc else []
+        grads = run_backward(out, w, xg, params)
+        d = {"meta": {"shape": list(shape), "dtype": dt, "n_bits": bits, "lwc": lwc, "edge": edge, "seed": seed,
+                      "big": big},
+             "scale": q.scale.detach().clone(), "x_sha": synth.sha(x)}
+        if lwc:
+            d["d_up"], d["d_low"] = grads[1].clone(), grads[2].clone()
+        if big:
+            rows = [0, 1, shape[0] // 2, shape[0] - 1]
+            d["rows"] = rows
+            pack_big(d, "out", out, rows)
+            pack_big(d, "dx", grads[0], rows)
+        else:
+            d["out"] = out.detach().clone()
+            d["dx"] = grads[0].clone()
+        cases[name] = d
+
+    for dt in ("f32", "f16"):
+        for bits in (2, 3, 4):
+            for lwc in (False, True):
+                one(f"e2_{dt}_b{bits}_{'lwc' if lwc else 'raw'}", (64, 96), dt, bits, lwc)
+        one(f"e2_{dt}_b3_lwc_edge", (12, 64), dt, 3, True, edge=True)
+        one(f"e2_{dt}_b3_raw_edge", (12, 64), dt, 3, False, edge=True)
+    one("e2_f32_b3_lwc_768x768", (768, 768), "f32", 3, True, big=True)
+    return cases
+
+
+def gen_mix(ref):
+    cases = {}
+    Q = ref.mix.MixAffineQuantizer
+
+    def one(name, shape, sym, lwc, hard, threshold=0.0, edge=False, seed=41, group=None, nb=None):
+        x, up, low, w = weight_case_inputs(shape, F32, edge, lwc, n_groups(shape, group), seed)
+        nb0 = synth.mix_bits(n_groups(shape, group), 3.0, seed + 3) if nb is None else nb
+        q = Q(target_bit=3, n_bits=nb0.clone(), hard_assign=hard, threshold=threshold, symmetric=sym,
+              per_channel_axes=[0], metric="minmax", dynamic=True, dynamic_method="per_channel",
+              group_size=group, shape=shape, lwc=lwc)
+        if lwc:
+            set_lwc(q, up, low)
+        xg = x.clone().requires_grad_(True)
+        out = q(xg)
+        params = [q.n_bits] + ([q.upbound_factor, q.lowbound_factor] if lwc else [])
+        grads = run_backward(out, w, xg, params)
+        with cuda_means_cpu():
+            msize, tsize = q.model_size_loss()
+        d = {"meta": {"shape": list(shape), "dtype": "f32", "symmetric": sym, "lwc": lwc, "hard": hard,
+                      "threshold": threshold, "edge": edge, "seed": seed, "group_size": group or 0},
+             "n_bits_in": nb0.clone(), "n_bits_after": q.n_bits.detach().clone(),
+             "out": out.detach().clone(), "dx": grads[0].clone(), "d_nbits": grads[1].clone(),
+             "model_size": msize.detach().clone(), "target_size": tsize.detach().clone(), "x_sha": synth.sha(x)}
+        if lwc:
+            d["d_up"], d["d_low"] = grads[2].clone(), grads[3].clone()
+        cases[name] = d
+
+    for sym in (False, True):
+        for lwc in (False, True):
+            for hard in (False, True):
+                one(f"m1_{'sym' if sym else 'asym'}_{'lwc' if lwc else 'raw'}_{'hard' if hard else 'soft'}",
+                    (64, 96), sym, lwc, hard)
+    one("m1_asym_lwc_hard_thr", (64, 96), False, True, True, threshold=0.3)
+    one("m1_asym_lwc_soft_edge", (20, 64), False, True, False, edge=True)
+    # bit-widths outside [2, 8] and on integers (floor == ceil) to pin the clamp and the blend
+    nb = torch.tensor([[1.2], [2.0], [3.0], [7.9], [8.0], [9.5], [4.5], [5.25]])
+    one("m1_asym_lwc_soft_clampbits", (8, 64), False, True, False, nb=nb)
+    return cases
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_act(ref):
+    cases = {}
+    Q = ref.uni.UniformAffineQuantizer
+
+    def one(name, shape, dt, bits, method, metric, cluster_dim=None, counts=None, calls=3, seed=51):
+        dtype = DT[dt]
+        q = Q(n_bits=bits, symmetric=False, per_channel_axes=[], metric=metric, dynamic=False,
+              dynamic_method=method)
+        q.cluster_dim = cluster_dim
+        q.cluster_counts = None if counts is None else np.array(counts)
+        d = {"meta": {"shape": list(shape), "dtype": dt, "n_bits": bits, "method": method, "metric": metric,
+                      "cluster_dim": -1 if cluster_dim is None else cluster_dim,
+                      "counts": [] if counts is None else list(counts), "calls": calls, "seed": seed}}
+        for c in range(calls):
+            x = synth.activation(shape, seed + c, dtype)
+            if c == 0:
+                xg = x.clone().requires_grad_(True)
+                out = q(xg)
+                w = synth.grad_like(x, seed + 100)
+                (dx,) = torch.autograd.grad((out.float() * w.float()).sum(), [xg])
+                d["dx0"] = dx.clone()
+                q.free()  # the training loop drops the cache (and its graph) after each step
+                with torch.no_grad():
+                    out = q(x)
+            else:
+                with torch.no_grad():
+                    out = q(x)
+            d[f"out{c}"] = out.detach().clone()
+            d[f"scale{c}"] = q.scale.detach().clone()
+            d[f"zp{c}"] = q.zero_point.detach().clone()
+            d[f"rzp{c}"] = q.round_zero_point.detach().clone()
+            d[f"cmin{c}"] = q.cached_xmin.detach().clone()
+            d[f"cmax{c}"] = q.cached_xmax.detach().clone()
+        q.set_eval_mode()
+        x = synth.activation(shape, seed + 77, dtype)
+        xg = x.clone().requires_grad_(True)
+        out = q(xg)
+        w = synth.grad_like(x, seed + 101)
+        (dx,) = torch.autograd.grad((out.float() * w.float()).sum(), [xg])
+        d["out_eval"] = out.detach().clone()
+        d["dx_eval"] = dx.clone()
+        cases[name] = d
+
+    for dt in ("f32", "f16"):
+        for bits in (4, 8):
+            for metric in ("minmax", "ema_minmax"):
+                one(f"a_{dt}_b{bits}_tensor_{metric}", (2, 32, 64), dt, bits, "per_tensor", metric)
+                one(f"a_{dt}_b{bits}_cluster3d_{metric}", (2, 32, 64), dt, bits, "per_cluster", metric, 2, [16] * 4)
+                one(f"a_{dt}_b{bits}_cluster2d_{metric}", (64, 96), dt, bits, "per_cluster", metric, 1, [24] * 4)
+        one(f"a_{dt}_b4_cluster3d_leftover", (1, 48, 70), dt, 4, "per_cluster", "ema_minmax", 2, [16] * 4)
+        one(f"a_{dt}_b4_cluster_nodim", (1, 48, 64), dt, 4, "per_cluster", "minmax", None, None)
+        one(f"a_{dt}_b4_cluster3d_percluster1", (1, 40, 32), dt, 4, "per_cluster", "minmax", 2, [1] * 32)
+        one(f"a_{dt}_b4_cluster2d_uneven", (40, 48), dt, 4, "per_cluster", "minmax", 1, [8, 24, 16])
+    return cases
+
+
+def gen_reorder(ref):
+    cases = {}
+    R = ref.reorder
+
+    def idx_case(name, c, n_clusters, n_heads, as_list=False, seed=61):
+        g = synth.gen(seed)
+        # tie-free ranges on an exact 2^-8 grid: range_i = 1 + perm_i/256, xmin_i = -k_i/256
+        xmin = -(torch.randint(1, 1024, (c,), generator=g).float() / 256)
+        xmax = (1 + torch.randperm(c, generator=g).float() / 256) + xmin
+        if as_list:
+            kmax = torch.rand(c, generator=g) * 4 + 1
+            kmin = -(torch.rand(c, generator=g) * 4 + 1)
+            index, counts = R.tensor_calc_reorder_index([xmax, kmax], [xmin, kmin], n_clusters, n_heads)
+        else:
+            kmax = kmin = torch.zeros(0)
+            index, counts = R.tensor_calc_reorder_index(xmax, xmin, n_clusters, n_heads)
+        rng = xmax - xmin
+        assert torch.unique(rng).numel() == c, "tie-free ranges expected"
+        cases[name] = {"meta": {"c": c, "n_clusters": n_clusters, "n_heads": n_heads or 0, "as_list": as_list, "seed": seed},
+                       "xmax": xmax, "xmin": xmin, "kmax": kmax, "kmin": kmin,
+                       "index": index.clone(), "counts": torch.from_numpy(np.asarray(counts)).clone()}
+
+    idx_case("r_768_c32_h1", 768, 32, None)
+    idx_case("r_768_c4_h12", 768, 4, 12)
+    idx_case("r_768_c4_h12_list", 768, 4, 12, as_list=True)
+    idx_case("r_3072_c32_h1", 3072, 32, None)
+    idx_case("r_4096_c4_h32", 4096, 4, 32)
+    idx_case("r_70_c4_h1", 70, 4, 1)
+
+    # statistics hooks: two calls accumulate a running max/min (3-D then 3-D; 2-D input hook)
+    def hook_case(name, shapes, dt, which, seed=71):
+        dtype = DT[dt]
+        R.oc_maxmin_dict.clear()
+        R.ic_maxmin_dict.clear()
+        m = types.SimpleNamespace(name="probe")
+        d = {"meta": {"shapes": [list(s) for s in shapes], "dtype": dt, "which": which, "seed": seed}}
+        for k, s in enumerate(shapes):
+            t = synth.activation(s, seed + k, dtype)
+            if which == "out":
+                R.layer_omax_hook(m, (), t)
+            else:
+                R.layer_i0max_hook(m, (t,), None)
+        store = R.oc_maxmin_dict if which == "out" else R.ic_maxmin_dict
+        d["max"], d["min"] = store["probe"][0].clone(), store["probe"][1].clone()
+        cases[name] = d
+        R.oc_maxmin_dict.clear()
+        R.ic_maxmin_dict.clear()
+
+    hook_case("h_out_3d_f16", [(1, 48, 64), (1, 48, 64), (1, 48, 64)], "f16", "out")
+    hook_case("h_in_2d_f16", [(48, 96), (48, 96)], "f16", "in")
+    hook_case("h_out_3d_f32", [(2, 24, 64), (2, 24, 64)], "f32", "out")
+
+    # R1..R5 wiring on real module objects of the reference
+    def wiring_case(name, seed=81):
+        H, Fd, heads = 64, 128, 4
+        g = synth.gen(seed)
+
+        def lin(i, o):
+            l = torch.nn.Linear(i, o)
+            with torch.no_grad():
+                l.weight.copy_(torch.randn(o, i, generator=g) * 0.05)
+                l.bias.copy_(torch.randn(o, generator=g) * 0.1)
+            return l
+
+        def ln(c):
+            l = torch.nn.LayerNorm(c)
+            with torch.no_grad():
+                l.weight.copy_(torch.rand(c, generator=g) + 0.5)
+                l.bias.copy_(torch.randn(c, generator=g) * 0.1)
+            return l
+
+        wq = {"n_bits": 4, "per_channel_axes": [0], "symmetric": False, "dynamic_method": "per_channel",
+              "group_size": None, "lwc": True, "dynamic": True, "metric": "minmax", "target_bit": 4}
+        aq = {"n_bits": 4, "per_channel_axes": [], "symmetric": False, "dynamic_method": "per_cluster",
+              "dynamic": False, "metric": "minmax"}
+        QL, QM, OLN = ref.int_linear.QuantLinear, ref.int_matmul.QuantMatMul, ref.omni_norm.OmniLayerNorm
+        ln1, ln2 = OLN(ln(H)), OLN(ln(H))
+        q, k, v, o = (QL(lin(H, H), wq, aq) for _ in range(4))
+        fc1, fc2 = QL(lin(H, Fd), wq, aq), QL(lin(Fd, H), wq, aq)
+        qkt = QM(aq, aq, matmul_func=torch.bmm)
+        pv = QM({"n_bits": 16, "metric": "fix0to1"}, aq, matmul_func=torch.bmm)
+        d = {"meta": {"H": H, "F": Fd, "heads": heads, "seed": seed}}
+        mods = {"ln1": ln1, "ln2": ln2, "q": q, "k": k, "v": v, "o": o, "fc1": fc1, "fc2": fc2}
+        for n, m in mods.items():
+            d[f"pre_{n}_w"] = m.weight.detach().clone()
+            d[f"pre_{n}_b"] = m.bias.detach().clone()
+        i1 = synth.permutation(H, seed + 1)
+        i2 = torch.cat([synth.permutation(H // heads, seed + 2 + h) + h * (H // heads) for h in range(heads)])
+        i3 = torch.cat([synth.permutation(H // heads, seed + 12 + h) + h * (H // heads) for h in range(heads)])
+        i4 = synth.permutation(H, seed + 4)
+        i5 = synth.permutation(Fd, seed + 5)
+        c1 = np.array([H // 8] * 8)
+        c2 = np.array([H // heads // 2] * (2 * heads))
+        c5 = np.array([Fd // 8] * 8)
+        R.R1_reorder(ln1, q, k, v, i1, c1)
+        R.R2_reorder(q, k, qkt, i2, c2)
+        R.R3_reorder(v, pv, o, i3, c2)
+        R.R4_reorder(ln2, fc1, i4, c1)
+        R.R5_reorder(fc1, fc2, i5, c5)
+        for n, t in (("i1", i1), ("i2", i2), ("i3", i3), ("i4", i4), ("i5", i5)):
+            d[n] = t.clone()
+        d["c1"], d["c2"], d["c5"] = (torch.from_numpy(c) for c in (c1, c2, c5))
+        for n, m in mods.items():
+            d[f"post_{n}_w"] = m.weight.detach().clone()
+            d[f"post_{n}_b"] = m.bias.detach().clone()
+        d["ln1_reorder_index"] = ln1.reorder_index.clone()
+        d["ln2_reorder_index"] = ln2.reorder_index.clone()
+        # cluster wiring as (dim, counts) pairs
+        wired = {"q_act": q.act_quantizer, "k_act": k.act_quantizer, "v_act": v.act_quantizer,
+                 "o_act": o.act_quantizer, "fc1_act": fc1.act_quantizer, "fc2_act": fc2.act_quantizer,
+                 "qkt_x1": qkt.x1_quantizer, "qkt_x2": qkt.x2_quantizer, "pv_x1": pv.x1_quantizer,
+                 "pv_x2": pv.x2_quantizer}
+        for n, qq in wired.items():
+            d[f"wire_{n}_dim"] = -1 if qq.cluster_dim is None else int(qq.cluster_dim)
+            d[f"wire_{n}_counts"] = (torch.zeros(0, dtype=torch.int64) if qq.cluster_counts is None
+                                     else torch.from_numpy(np.asarray(qq.cluster_counts)).clone())
+        # forward of the reordered layer norm (gather + layer_norm), 3-D and 2-D
+        x3 = synth.activation((2, 8, H), seed + 20)
+        d["x3"] = x3
+        d["ln1_out3"] = ln1(x3).detach().clone()
+        x2 = synth.activation((16, H), seed + 21)
+        d["x2"] = x2
+        d["ln2_out2"] = ln2(x2).detach().clone()
+        # QuantLinear forward with weight+act quant on after wiring (first calibration call)
+        q.set_quant_state(True, True)
+        y = q(d["ln1_out3"])
+        d["q_out3"] = y.detach().clone()
+        fc1.set_quant_state(True, True)
+        d["fc1_out2"] = fc1(d["ln2_out2"]).detach().clone()
+        cases[name] = d
+
+    wiring_case("wiring_small")
+    return cases
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    ref = import_reference(args.ref)
+    fams = {"uniform": gen_uniform, "mix2": gen_mix2, "exp1": gen_exp1, "exp2": gen_exp2, "mix": gen_mix,
+            "act": gen_act, "reorder": gen_reorder}
+    for fam, fn in fams.items():
+        if args.only and fam not in args.only.split(","):
+            continue
+        cases = fn(ref)
+        path = os.path.join(HERE, f"{fam}.pt")
+        torch.save(cases, path)
+        print(f"{fam}: {len(cases)} cases -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    main()
