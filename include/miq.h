@@ -1,0 +1,79 @@
+/*
+ * libmiq — C ABI of the MI355X (gfx950) fake-quantization kernels.
+ *
+ * The reference has no FFI layer: its hot path is a set of torch.nn.Module classes that issue
+ * dozens of eager PyTorch ops per call.  Each entry point below replaces the op sequence of one
+ * reference method (cited per function, paths relative to the reference tree) with one or two
+ * fused HIP kernels.  A binding needs nothing but device pointers, sizes and a stream:
+ *
+ *   - all pointers are DEVICE pointers owned by the caller (inputs are only read, outputs are
+ *     fully overwritten); nothing is allocated, freed or retained by the library;
+ *   - `dtype` is MIQ_F32 or MIQ_F16 and applies to every `void*` tensor of the call; fp16 tensors
+ *     are computed in fp32 with a rounding to fp16 after every elementwise step, which reproduces
+ *     PyTorch's per-op materialisation bit for bit;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work and never
+ *     synchronise;
+ *   - return value: 0 on success, a negative errno-style code otherwise (-22 bad argument,
+ *     -5 launch failure); miq_last_error() returns the text for the calling thread.
+ *
+ * Row geometry shared by the row-wise ("per output channel") quantizers: the tensor is a row-major
+ * [O, I] matrix.  With `group` == 0 every matrix row is one quantization row.  With `group` > 0
+ * every matrix row is cut into ceil(I/group) groups; a short last group is zero-padded for the
+ * min/max statistics only (reference quantizer.py:249-255, the padding never reaches the output).
+ * Per-row vectors (up, low, scale, rzp, ...) have O*ceil(I/group) entries.
+ */
+#ifndef MIQ_H_
+#define MIQ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIQ_F32 0
+#define MIQ_F16 1
+
+/* flags of miq_rowquant_uniform_* */
+#define MIQ_CLAMP_ASYM_SCALE 1 /* clamp the asymmetric scale to [1e-5, 1e4] (quantizer_mix_v2.py:140) */
+#define MIQ_LWC_PREACTIVATED 2 /* up/low already hold sigmoid(factor) in (0,1); d_up/d_low are then the
+                                  gradients w.r.t. those values.  Results are a pure function of IEEE
+                                  add/mul/div/round and therefore bit-reproducible on any device; without
+                                  the flag the kernel evaluates 1/(1+expf(-f)) itself, whose last bit
+                                  depends on the math library. */
+
+int miq_version(void);
+const char* miq_last_error(void);
+
+/*
+ * Uniform affine fake quantization of matrix rows with optional learnable weight clipping.
+ * Replaces UniformAffineQuantizer.per_token_dynamic_calibration + fake_quant
+ * (quantize/quantizer.py:248-273 and :99-121); with `row_bits` != NULL it is
+ * Mix2AffineQuantizer.forward (quantize/quantizer_mix_v2.py:116-146).
+ *   x         [O, I]            input
+ *   up, low   [rows] or NULL    raw LWC factors (sigmoid is applied inside), both or neither
+ *   row_bits  [rows] f32|NULL   per-row integer bit-widths; overrides n_bits
+ *   out       [O, I]            dequantized result
+ *   scale_out, rzp_out [rows]   scale and rounded zero point that were used
+ *   codes_out [O, I] u8 | NULL  clamped integer levels (n_bits <= 8); 0 where the level is NaN
+ */
+int miq_rowquant_uniform_fwd(const void* x, const void* up, const void* low, const float* row_bits,
+                             void* out, void* scale_out, void* rzp_out, void* codes_out,
+                             int64_t O, int64_t I, int64_t group, int n_bits, int symmetric,
+                             int flags, int dtype, void* stream);
+
+/*
+ * Backward of the above: what autograd derives from round_ste (quantize/quantizer.py:13-17)
+ * through amin/amax, sigmoid and the scale.  Statistics are recomputed from x.
+ *   grad_out [O, I]; dx [O, I] or NULL (skip the input gradient); d_up, d_low [rows] (required
+ *   iff up/low are given).
+ */
+int miq_rowquant_uniform_bwd(const void* grad_out, const void* x, const void* up, const void* low,
+                             const float* row_bits, void* dx, void* d_up, void* d_low,
+                             int64_t O, int64_t I, int64_t group, int n_bits, int symmetric,
+                             int flags, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIQ_H_ */

@@ -1,0 +1,219 @@
+// Shared device-side building blocks for the fake-quantization kernels (gfx950 / CDNA4, wave64).
+//
+// Numerics contract (matches PyTorch's CPU kernels op by op):
+//   * every elementwise op is computed in fp32 and, for fp16 tensors, rounded to fp16 right after
+//     the op (rnd<T>()), because PyTorch materialises a half tensor after each op;
+//   * division is IEEE-correct fp32 division (hipcc's default), rounding is round-half-to-even;
+//   * min/max reductions and clamps propagate NaN the way torch.amin/amax/clamp do.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define MIQ_F32 0
+#define MIQ_F16 1
+
+namespace miq {
+
+constexpr float kClipLo = 1e-5f;   // CLIPMIN of the reference (quantize/quantizer.py:10)
+constexpr float kClipHi = 1e4f;
+
+// ---------------------------------------------------------------------------------------------
+// per-dtype rounding / conversion
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float rnd(float v);
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<__half>(float v) { return __half2float(__float2half(v)); }
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __half2float(v); }
+
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
+
+// widest vector (16 bytes) per dtype
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<__half> { static constexpr int N = 8; };
+
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> ld_pack(const T* p) {
+    return *reinterpret_cast<const Pack<T, VEC>*>(p);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void st_pack(T* p, const Pack<T, VEC>& v) {
+    *reinterpret_cast<Pack<T, VEC>*>(p) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NaN-propagating min / max / clamp (torch semantics)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nmin(float a, float b) { return (b < a || b != b) ? b : a; }
+__device__ __forceinline__ float nmax(float a, float b) { return (b > a || b != b) ? b : a; }
+// std::min(std::max(v, lo), hi): NaN stays NaN
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+    v = (v < lo) ? lo : v;
+    return (hi < v) ? hi : v;
+}
+__device__ __forceinline__ float sgnf(float v) { return (float)((0.f < v) - (v < 0.f)); }
+
+// sigmoid exactly as 1/(1+exp(-x)) in fp32 (ATen's formula), rounded to T
+template <typename T> __device__ __forceinline__ float sigmoid_t(float x) {
+    return rnd<T>(1.0f / (1.0f + expf(-x)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// team reductions.  A "team" is TEAM consecutive threads that own one quantization row.
+// TEAM <= 64: shuffle only (team lies inside one wave).  TEAM > 64: TEAM == blockDim.x, LDS exchange.
+// ---------------------------------------------------------------------------------------------
+// lds: >= 16*K floats of shared memory, only touched when TEAM > 64
+template <int TEAM, int K, class F>
+__device__ __forceinline__ void team_reduce(float (&v)[K], F f, float* lds) {
+    constexpr int W = TEAM < 64 ? TEAM : 64;
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = f(k, v[k], __shfl_xor(v[k], o));
+    }
+    if constexpr (TEAM > 64) {
+        constexpr int NW = TEAM / 64;
+        const int wid = threadIdx.x >> 6;
+        __syncthreads();  // protects lds against the previous reduction's readers
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) lds[k * 16 + wid] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float r = lds[k * 16];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) r = f(k, r, lds[k * 16 + w]);
+            v[k] = r;
+        }
+    }
+}
+
+// element 0 is a running minimum, element 1 a running maximum (both NaN-propagating)
+struct OpMinMax {
+    __device__ float operator()(int k, float a, float b) const { return k == 0 ? nmin(a, b) : nmax(a, b); }
+};
+struct OpAdd {
+    __device__ float operator()(int, float a, float b) const { return a + b; }
+};
+
+template <int TEAM, int K>
+__device__ __forceinline__ void team_sum(float (&v)[K], float* lds) { team_reduce<TEAM, K>(v, OpAdd(), lds); }
+
+// ---------------------------------------------------------------------------------------------
+// Row geometry: how quantization rows map onto a row-major [O, I] matrix.
+//   G == 1              : rows are matrix rows of length I (g == I)
+//   G  > 1              : every matrix row is cut into G groups of g elements; the last group of a
+//                         row may be short (I - (G-1)*g elements) and is zero-padded to g for the
+//                         statistics only (padding never reaches the output).
+// ---------------------------------------------------------------------------------------------
+struct RowGeom {
+    long long n_rows;  // O * G
+    int I;             // matrix columns
+    int g;             // nominal row (group) length
+    int G;             // groups per matrix row
+};
+
+__device__ __forceinline__ void row_span(const RowGeom& geo, long long row, long long& base, int& len) {
+    if (geo.G == 1) {
+        base = row * (long long)geo.I;
+        len = geo.I;
+    } else {
+        const long long r = row / geo.G;
+        const int j = (int)(row - r * geo.G);
+        base = r * (long long)geo.I + (long long)j * geo.g;
+        const int rest = geo.I - j * geo.g;
+        len = rest < geo.g ? rest : geo.g;
+    }
+}
+
+// A row held in registers by its team: thread t owns packs t, t+TEAM, t+2*TEAM, ...
+template <typename T, int VEC, int TEAM, int NV>
+struct RowTile {
+    Pack<T, VEC> v[NV];
+    int npack;  // packs in this row
+    int t;      // lane inside the team
+
+    __device__ __forceinline__ void load(const T* base, int len, int lane) {
+        t = lane;
+        npack = len / VEC;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = k * TEAM + t;
+            if (j < npack) v[k] = ld_pack<T, VEC>(base + (long long)j * VEC);
+        }
+    }
+    template <class F> __device__ __forceinline__ void for_each(F f) const {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = k * TEAM + t;
+            if (j < npack) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f(k, e, to_f<T>(v[k].e[e]));
+            }
+        }
+    }
+    __device__ __forceinline__ bool has(int k) const { return k * TEAM + t < npack; }
+    __device__ __forceinline__ long long offset(int k) const { return (long long)(k * TEAM + t) * VEC; }
+};
+
+// Row min/max over the team (NaN-propagating), including the implicit zero padding.
+template <typename T, int VEC, int TEAM, int NV>
+__device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, bool padded, float* lds,
+                                           float& rmin, float& rmax) {
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    x.for_each([&](int, int, float a) { mn = nmin(mn, a); mx = nmax(mx, a); });
+    if (padded) { mn = nmin(mn, 0.f); mx = nmax(mx, 0.f); }
+    float mm[2] = {mn, mx};
+    team_reduce<TEAM, 2>(mm, OpMinMax(), lds);
+    rmin = mm[0];
+    rmax = mm[1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launch helper: pick (TEAM, NV) from the number of 16-byte packs in the longest row.
+// ---------------------------------------------------------------------------------------------
+#define MIQ_ROW_DISPATCH(NPACK, LAUNCH)                                  \
+    do {                                                                 \
+        if ((NPACK) <= 16) { LAUNCH(16, 1); }                            \
+        else if ((NPACK) <= 64) { LAUNCH(16, 4); }                       \
+        else if ((NPACK) <= 256) { LAUNCH(64, 4); }                      \
+        else if ((NPACK) <= 1024) { LAUNCH(256, 4); }                    \
+        else if ((NPACK) <= 4096) { LAUNCH(1024, 4); }                   \
+        else { LAUNCH(1024, 8); }                                        \
+    } while (0)
+
+constexpr int kRowMaxPacks = 8192;
+
+template <int TEAM> constexpr int block_of() { return TEAM > 256 ? TEAM : 256; }
+
+}  // namespace miq
+
+// error reporting shared by all translation units (defined in capi.hip)
+extern "C" void miq_set_error(const char* fmt, ...);
+
+#define MIQ_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            miq_set_error(__VA_ARGS__);          \
+            return -22; /* -EINVAL */            \
+        }                                        \
+    } while (0)
+
+#define MIQ_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            miq_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));        \
+            return -5; /* -EIO */                                                       \
+        }                                                                               \
+    } while (0)
