@@ -73,6 +73,62 @@ int miq_rowquant_uniform_bwd(const void* grad_out, const void* x, const void* up
                              int64_t O, int64_t I, int64_t group, int n_bits, int symmetric,
                              int flags, int dtype, void* stream);
 
+/*
+ * Static activation quantisation over the channel (last) axis of a row-major [R, C] slab.
+ * Replaces UniformAffineQuantizer.per_cluster_minmax_calibration / per_tensor_minmax_calibration /
+ * calibration (quantize/quantizer.py:157-238): one streaming pass for the statistics instead of
+ * two reductions plus a Python loop of four kernels per cluster.
+ *
+ * miq_colstat_chunks   number of row chunks the statistics pass will use for this shape
+ * miq_colstat_minmax   per-channel min/max of every row chunk -> part_min/part_max [nchunk, C] f32
+ * miq_cluster_scale    fold the chunks (taking column idx[c] for output channel c when idx is
+ *                      given), combine with the cached statistics (metric 0: running min/max,
+ *                      1: 0.99/0.01 EMA; cached_* may be NULL), merge channels into the contiguous
+ *                      clusters described by starts[0..n_clusters] (prefix sums; channels from
+ *                      `covered` on keep per-channel statistics), then
+ *                      scale = clamp((max-min)/(2^n-1), 1e-5, 1e4), zp = clamp(-min/scale, +-1e4),
+ *                      rzp = round(zp).  part_min/part_max must have (nchunk+1)*C floats: row
+ *                      `nchunk` receives the per-channel statistics before the merge (kept by the
+ *                      caller for the backward pass).  Outputs are [C] vectors of `dtype`.
+ *                      idx entries must lie in [0, C).
+ */
+int miq_colstat_chunks(int64_t R, int64_t C, int dtype);
+int miq_colstat_minmax(const void* x, int64_t R, int64_t C, float* part_min, float* part_max,
+                       int nchunk, int dtype, void* stream);
+int miq_cluster_scale(float* part_min, float* part_max, int nchunk, int64_t C, const int* idx,
+                      const void* cached_min, const void* cached_max, int metric, const int* starts,
+                      int n_clusters, int64_t covered, int n_bits, void* cmin_out, void* cmax_out,
+                      void* scale_out, void* zp_out, void* rzp_out, int dtype, void* stream);
+
+/*
+ * Quantize-dequantize with per-channel scale / rounded zero point vectors [C]
+ * (UniformAffineQuantizer.fake_quant with the calibrated buffers, quantize/quantizer.py:99-121,140).
+ * codes_out: optional u8 [R, C] clamped levels (n_bits <= 8).
+ */
+int miq_colquant_fwd(const void* x, const void* scale, const void* rzp, void* out, void* codes_out,
+                     int64_t R, int64_t C, int n_bits, int dtype, void* stream);
+
+/*
+ * Backward of calibration + fake_quant as autograd derives it from round_ste
+ * (quantize/quantizer.py:13-17).  With chan_min/chan_max == NULL the scales are constants (eval
+ * mode) and dx = grad_out * [level inside the grid].  Otherwise the scale gradient is summed per
+ * cluster and routed to the extreme elements: chan_min/chan_max are the per-channel statistics
+ * (row `nchunk` of miq_cluster_scale's partial buffers), kmin/kmax the merged [C] statistics,
+ * workspace has (3*nchunk + 2)*C floats with nchunk = miq_colstat_chunks(R, C, dtype).
+ */
+int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, const void* rzp,
+                     const float* chan_min, const float* chan_max, const void* kmin, const void* kmax,
+                     const int* starts, int n_clusters, int64_t covered, float* workspace, int nchunk,
+                     void* dx, int64_t R, int64_t C, int n_bits, int dtype, void* stream);
+
+/*
+ * RPTQ channel reorder: out[r, c] = x[r, idx[c]] (torch.index_select on the last axis, as in
+ * OmniLayerNorm.forward, quantize/omni_norm.py:36-40).  Rows are staged through LDS so that both
+ * the global loads and the global stores stay coalesced.  idx: int32 [C], entries in [0, C).
+ */
+int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int64_t C, int dtype,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

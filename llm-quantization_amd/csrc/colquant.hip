@@ -1,0 +1,399 @@
+// Static activation quantisation over the channel (last) axis of a [R, C] activation slab:
+//   k_colstat        per-channel min/max over the R rows            (reads x once)
+//   k_cluster_scale  combine with the cached statistics (running min/max or EMA), merge channels
+//                    into contiguous clusters, derive scale / zero point per channel
+//   k_colquant_fwd   quantize-dequantize with the per-channel parameters (reads x, writes out)
+//   k_colquant_bwd   straight-through backward incl. the min/max routing
+//   k_gather_*       RPTQ channel reorder: out[r, c] = x[r, idx[c]] staged through LDS
+//
+// Semantics: UniformAffineQuantizer.per_cluster_minmax_calibration / per_tensor_minmax_calibration /
+// calibration / fake_quant (reference quantize/quantizer.py:157-238,99-121) and the index_select in
+// OmniLayerNorm.forward (quantize/omni_norm.py:36-40).
+#include "miq_common.h"
+
+namespace miq {
+
+// ---------------------------------------------------------------------------------------------
+// per-channel min/max.  Block = 4 waves; lane l owns one 16-byte pack of columns, wave w owns every
+// 4th row of the block's row chunk, so each wave-load is one contiguous 1 KiB line segment.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_colstat(const T* __restrict__ x, long long R, int C, int rows_per_chunk, float* __restrict__ pmin,
+          float* __restrict__ pmax) {
+    __shared__ float smin[4][64 * VEC];
+    __shared__ float smax[4][64 * VEC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    const bool valid = col0 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float mn[VEC], mx[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mn[e] = __builtin_inff(); mx[e] = -__builtin_inff(); }
+    if (valid) {
+        const T* p = x + col0;
+        long long r = r0 + w;
+        for (; r + 12 < r1; r += 16) {
+            Pack<T, VEC> a = ld_pack<T, VEC>(p + r * C);
+            Pack<T, VEC> b = ld_pack<T, VEC>(p + (r + 4) * C);
+            Pack<T, VEC> c = ld_pack<T, VEC>(p + (r + 8) * C);
+            Pack<T, VEC> d = ld_pack<T, VEC>(p + (r + 12) * C);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float fa = to_f<T>(a.e[e]), fb = to_f<T>(b.e[e]), fc = to_f<T>(c.e[e]), fd = to_f<T>(d.e[e]);
+                mn[e] = nmin(nmin(mn[e], fa), nmin(fb, nmin(fc, fd)));
+                mx[e] = nmax(nmax(mx[e], fa), nmax(fb, nmax(fc, fd)));
+            }
+        }
+        for (; r < r1; r += 4) {
+            Pack<T, VEC> a = ld_pack<T, VEC>(p + r * C);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float fa = to_f<T>(a.e[e]);
+                mn[e] = nmin(mn[e], fa);
+                mx[e] = nmax(mx[e], fa);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        smin[w][lane * VEC + e] = mn[e];
+        smax[w][lane * VEC + e] = mx[e];
+    }
+    __syncthreads();
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int i = lane * VEC + e;
+            const float a = nmin(nmin(smin[0][i], smin[1][i]), nmin(smin[2][i], smin[3][i]));
+            const float b = nmax(nmax(smax[0][i], smax[1][i]), nmax(smax[2][i], smax[3][i]));
+            pmin[(long long)blockIdx.y * C + col0 + e] = a;
+            pmax[(long long)blockIdx.y * C + col0 + e] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cluster merge + scale.  One block per cluster (plus one block for channels that belong to no
+// cluster, which keep their own statistics).  `idx` (optional) maps an output channel to the source
+// column whose statistics it takes (reorder fused into the statistics pass).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct ScaleArgs {
+    float* pmin;         // [nchunk + 1, C] partial minima; row nchunk receives the per-channel result
+    float* pmax;
+    int nchunk;
+    int C;
+    const int* idx;      // [C] or nullptr
+    const T* cached_min; // [C] previous statistics or nullptr
+    const T* cached_max;
+    int metric;          // 0 running min/max, 1 EMA 0.99/0.01
+    const int* starts;   // [ncl + 1] prefix sums of the cluster sizes
+    int ncl;
+    int n_bits;
+    T* cmin_out;         // [C] statistics after combine + merge (what the caller caches)
+    T* cmax_out;
+    T* scale;            // [C]
+    T* zp;               // [C] clamped, un-rounded zero point
+    T* rzp;              // [C]
+};
+
+// step 1: one thread per output channel folds the row-chunk partials of its source column and
+// applies the running-min/max or EMA update against the cached statistics.
+template <typename T>
+__global__ void __launch_bounds__(256) k_colstat_combine(ScaleArgs<T> a) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    const int src = a.idx ? a.idx[c] : c;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (int j = 0; j < a.nchunk; ++j) {
+        mn = nmin(mn, a.pmin[(long long)j * a.C + src]);
+        mx = nmax(mx, a.pmax[(long long)j * a.C + src]);
+    }
+    if (a.cached_min) {
+        const float pm = to_f<T>(a.cached_min[c]), px = to_f<T>(a.cached_max[c]);
+        if (a.metric == 0) {
+            mx = nmax(px, mx);
+            mn = nmin(pm, mn);
+        } else {
+            mx = rnd<T>(rnd<T>(px * 0.99f) + rnd<T>(mx * 0.01f));
+            mn = rnd<T>(rnd<T>(pm * 0.99f) + rnd<T>(mn * 0.01f));
+        }
+    }
+    a.pmin[(long long)a.nchunk * a.C + c] = mn;
+    a.pmax[(long long)a.nchunk * a.C + c] = mx;
+}
+
+// step 2: one block per cluster (plus one block for channels that belong to no cluster)
+template <typename T>
+__global__ void __launch_bounds__(256) k_cluster_scale(ScaleArgs<T> a) {
+    __shared__ float lds[32];
+    const int k = blockIdx.x;
+    const bool own = k >= a.ncl;  // leftover channels: every channel is its own cluster
+    const int st = own ? a.starts[a.ncl] : a.starts[k];
+    const int en = own ? a.C : a.starts[k + 1];
+    const float* cmn = a.pmin + (long long)a.nchunk * a.C;
+    const float* cmx = a.pmax + (long long)a.nchunk * a.C;
+    float mm[2] = {__builtin_inff(), -__builtin_inff()};
+    if (!own) {
+        for (int c = st + threadIdx.x; c < en; c += 256) {
+            mm[0] = nmin(mm[0], cmn[c]);
+            mm[1] = nmax(mm[1], cmx[c]);
+        }
+        team_reduce<256, 2>(mm, OpMinMax(), lds);
+    }
+    const float qmax = exp2f((float)a.n_bits) - 1.0f;
+    const float lo = rnd<T>(kClipLo);
+    for (int c = st + threadIdx.x; c < en; c += 256) {
+        const float mn = own ? cmn[c] : mm[0];
+        const float mx = own ? cmx[c] : mm[1];
+        a.cmin_out[c] = from_f<T>(mn);
+        a.cmax_out[c] = from_f<T>(mx);
+        const float s = clampf(rnd<T>(rnd<T>(mx - mn) / qmax), lo, kClipHi);
+        const float z = clampf(rnd<T>(-mn / s), -kClipHi, kClipHi);
+        a.scale[c] = from_f<T>(s);
+        a.zp[c] = from_f<T>(z);
+        a.rzp[c] = from_f<T>(rintf(z));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// quantize-dequantize with per-channel parameters
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __restrict__ rzp,
+               T* __restrict__ out, uint8_t* __restrict__ codes, long long R, int C, int rows_per_chunk, float qmax) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    if (col0 >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float s[VEC], z[VEC];
+    {
+        Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s[e] = to_f<T>(ps.e[e]); z[e] = to_f<T>(pz.e[e]); }
+    }
+    auto body = [&](const Pack<T, VEC>& a, long long r) {
+        Pack<T, VEC> o;
+        Pack<uint8_t, VEC> cd;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float q = rnd<T>(to_f<T>(a.e[e]) / s[e]);
+            const float rr = rintf(q);
+            const float xi = rnd<T>(rnd<T>(rnd<T>(rr - q) + q) + z[e]);
+            const float xc = clampf(xi, 0.f, qmax);
+            o.e[e] = from_f<T>(rnd<T>(xc - z[e]) * s[e]);
+            cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+        }
+        st_pack<T, VEC>(out + r * C + col0, o);
+        if (codes) st_pack<uint8_t, VEC>(codes + r * C + col0, cd);
+    };
+    long long r = r0 + w;
+    for (; r + 12 < r1; r += 16) {
+        Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
+        Pack<T, VEC> b = ld_pack<T, VEC>(x + (r + 4) * C + col0);
+        Pack<T, VEC> c = ld_pack<T, VEC>(x + (r + 8) * C + col0);
+        Pack<T, VEC> d = ld_pack<T, VEC>(x + (r + 12) * C + col0);
+        body(a, r);
+        body(b, r + 4);
+        body(c, r + 8);
+        body(d, r + 12);
+    }
+    for (; r < r1; r += 4) {
+        Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
+        body(a, r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel gather out[r, c] = x[r, idx[c]]: rows are staged in LDS with coalesced 16-byte loads and
+// read back through the index, stores are coalesced again.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_gather(const T* __restrict__ x, const int* __restrict__ idx, T* __restrict__ out, long long R, int C, int rows_per_block) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    T* tile = reinterpret_cast<T*>(smem);  // [rows_per_block][C]
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    int nr = rows_per_block;
+    if (r0 + nr > R) nr = (int)(R - r0);
+    const int npack = C / VEC;
+    const long long total = (long long)nr * npack;
+    const T* src = x + r0 * C;  // the nr rows are contiguous in memory
+    for (long long i = threadIdx.x; i < total; i += 256)
+        st_pack<T, VEC>(tile + i * VEC, ld_pack<T, VEC>(src + i * VEC));
+    __syncthreads();
+    T* dst = out + r0 * C;
+    for (int p = threadIdx.x; p < npack; p += 256) {
+        int id[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) id[e] = idx[p * VEC + e];
+        for (int rr = 0; rr < nr; ++rr) {
+            Pack<T, VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.e[e] = tile[(long long)rr * C + id[e]];
+            st_pack<T, VEC>(dst + (long long)rr * C + (long long)p * VEC, o);
+        }
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static inline int pick_chunks(long long R, int col_tiles) {
+    // aim at ~2048 blocks, at least 16 rows per chunk
+    long long want = 2048 / (col_tiles > 0 ? col_tiles : 1);
+    if (want < 1) want = 1;
+    long long maxc = (R + 15) / 16;
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+template <typename T>
+static int launch_colstat(const void* x, long long R, long long C, float* pmin, float* pmax, int nchunk,
+                          hipStream_t stream) {
+    constexpr int N = VecOf<T>::N;
+    const bool vec_ok = (C % N == 0) && aligned16(x);
+    const int rows_per_chunk = (int)((R + nchunk - 1) / nchunk);
+    if (vec_ok) {
+        dim3 grid((unsigned)((C / N + 63) / 64), (unsigned)nchunk);
+        hipLaunchKernelGGL((k_colstat<T, N>), grid, dim3(256), 0, stream, (const T*)x, R, (int)C, rows_per_chunk, pmin, pmax);
+    } else {
+        dim3 grid((unsigned)((C + 63) / 64), (unsigned)nchunk);
+        hipLaunchKernelGGL((k_colstat<T, 1>), grid, dim3(256), 0, stream, (const T*)x, R, (int)C, rows_per_chunk, pmin, pmax);
+    }
+    MIQ_CHECK_LAUNCH("miq_colstat_minmax");
+    return 0;
+}
+
+template <typename T>
+static int launch_colquant_fwd(const void* x, const void* scale, const void* rzp, void* out, void* codes,
+                               long long R, long long C, int n_bits, hipStream_t stream) {
+    constexpr int N = VecOf<T>::N;
+    const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(out) && aligned16(scale) && aligned16(rzp) &&
+                        (!codes || (reinterpret_cast<uintptr_t>(codes) % N) == 0);
+    const float qmax = (float)((1 << n_bits) - 1);
+    if (vec_ok) {
+        const int tiles = (int)((C / N + 63) / 64);
+        const int nchunk = pick_chunks(R, tiles);
+        const int rpc = (int)((R + nchunk - 1) / nchunk);
+        hipLaunchKernelGGL((k_colquant_fwd<T, N>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x,
+                           (const T*)scale, (const T*)rzp, (T*)out, (uint8_t*)codes, R, (int)C, rpc, qmax);
+    } else {
+        const int tiles = (int)((C + 63) / 64);
+        const int nchunk = pick_chunks(R, tiles);
+        const int rpc = (int)((R + nchunk - 1) / nchunk);
+        hipLaunchKernelGGL((k_colquant_fwd<T, 1>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x,
+                           (const T*)scale, (const T*)rzp, (T*)out, (uint8_t*)codes, R, (int)C, rpc, qmax);
+    }
+    MIQ_CHECK_LAUNCH("miq_colquant_fwd");
+    return 0;
+}
+
+template <typename T>
+static int launch_gather(const void* x, const int* idx, void* out, long long R, long long C, hipStream_t stream) {
+    constexpr int N = VecOf<T>::N;
+    const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(out);
+    const long long row_bytes = C * (long long)sizeof(T);
+    MIQ_CHECK_ARG(row_bytes <= 160 * 1024, "miq_gather_lastdim: a row of %lld bytes does not fit in LDS", row_bytes);
+    int rows = (int)(65536 / row_bytes);
+    if (rows < 1) rows = 1;
+    if (rows > 16) rows = 16;
+    if (rows > R) rows = (int)R;
+    const size_t lds = (size_t)rows * row_bytes;
+    const unsigned grid = (unsigned)((R + rows - 1) / rows);
+    if (vec_ok) {
+        if (lds > 65536) hipFuncSetAttribute((const void*)k_gather<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gather<T, N>), dim3(grid), dim3(256), lds, stream, (const T*)x, idx, (T*)out, R, (int)C, rows);
+    } else {
+        if (lds > 65536) hipFuncSetAttribute((const void*)k_gather<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gather<T, 1>), dim3(grid), dim3(256), lds, stream, (const T*)x, idx, (T*)out, R, (int)C, rows);
+    }
+    MIQ_CHECK_LAUNCH("miq_gather_lastdim");
+    return 0;
+}
+
+}  // namespace miq
+
+using namespace miq;
+
+extern "C" int miq_colstat_chunks(int64_t R, int64_t C, int dtype) {
+    if (R <= 0 || C <= 0) return 1;
+    const int N = dtype == MIQ_F16 ? 8 : 4;
+    const int tiles = (int)((C % N == 0) ? (C / N + 63) / 64 : (C + 63) / 64);
+    return pick_chunks(R, tiles);
+}
+
+extern "C" int miq_colstat_minmax(const void* x, int64_t R, int64_t C, float* part_min, float* part_max,
+                                  int nchunk, int dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(x && part_min && part_max && R > 0 && C > 0 && C < (1ll << 31) && nchunk >= 1,
+                  "miq_colstat_minmax: null pointer or bad shape (R=%lld C=%lld nchunk=%d)", (long long)R, (long long)C, nchunk);
+    if (dtype == MIQ_F32) return launch_colstat<float>(x, R, C, part_min, part_max, nchunk, (hipStream_t)stream);
+    if (dtype == MIQ_F16) return launch_colstat<__half>(x, R, C, part_min, part_max, nchunk, (hipStream_t)stream);
+    miq_set_error("miq_colstat_minmax: unsupported dtype %d", dtype);
+    return -22;
+}
+
+template <typename T>
+static int cluster_scale_t(float* pmin, float* pmax, int nchunk, int64_t C, const int* idx,
+                           const void* cached_min, const void* cached_max, int metric, const int* starts, int ncl,
+                           int covered, int n_bits, void* cmin_out, void* cmax_out, void* scale, void* zp, void* rzp,
+                           hipStream_t stream) {
+    ScaleArgs<T> a;
+    a.pmin = pmin; a.pmax = pmax; a.nchunk = nchunk; a.C = (int)C; a.idx = idx;
+    a.cached_min = (const T*)cached_min; a.cached_max = (const T*)cached_max; a.metric = metric;
+    a.starts = starts; a.ncl = ncl; a.n_bits = n_bits;
+    a.cmin_out = (T*)cmin_out; a.cmax_out = (T*)cmax_out; a.scale = (T*)scale; a.zp = (T*)zp; a.rzp = (T*)rzp;
+    const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL((k_colstat_combine<T>), dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((k_cluster_scale<T>), dim3(grid), dim3(256), 0, stream, a);
+    MIQ_CHECK_LAUNCH("miq_cluster_scale");
+    return 0;
+}
+
+extern "C" int miq_cluster_scale(float* part_min, float* part_max, int nchunk, int64_t C, const int* idx,
+                                 const void* cached_min, const void* cached_max, int metric, const int* starts,
+                                 int n_clusters, int64_t covered, int n_bits, void* cmin_out, void* cmax_out,
+                                 void* scale_out, void* zp_out, void* rzp_out, int dtype, void* stream) {
+    if (C == 0) return 0;
+    MIQ_CHECK_ARG(part_min && part_max && starts && cmin_out && cmax_out && scale_out && zp_out && rzp_out,
+                  "miq_cluster_scale: null pointer");
+    MIQ_CHECK_ARG((cached_min == nullptr) == (cached_max == nullptr), "miq_cluster_scale: cached min/max must come together");
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && (metric == 0 || metric == 1) && n_clusters >= 0 && covered >= 0 && covered <= C,
+                  "miq_cluster_scale: bad n_bits/metric/cluster layout");
+    if (dtype == MIQ_F32)
+        return cluster_scale_t<float>(part_min, part_max, nchunk, C, idx, cached_min, cached_max, metric, starts,
+                                      n_clusters, (int)covered, n_bits, cmin_out, cmax_out, scale_out, zp_out, rzp_out, (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return cluster_scale_t<__half>(part_min, part_max, nchunk, C, idx, cached_min, cached_max, metric, starts,
+                                       n_clusters, (int)covered, n_bits, cmin_out, cmax_out, scale_out, zp_out, rzp_out, (hipStream_t)stream);
+    miq_set_error("miq_cluster_scale: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_colquant_fwd(const void* x, const void* scale, const void* rzp, void* out, void* codes_out,
+                                int64_t R, int64_t C, int n_bits, int dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(x && scale && rzp && out && R > 0 && C > 0 && C < (1ll << 31), "miq_colquant_fwd: null pointer or bad shape");
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && (!codes_out || n_bits <= 8), "miq_colquant_fwd: n_bits=%d unsupported", n_bits);
+    if (dtype == MIQ_F32) return launch_colquant_fwd<float>(x, scale, rzp, out, codes_out, R, C, n_bits, (hipStream_t)stream);
+    if (dtype == MIQ_F16) return launch_colquant_fwd<__half>(x, scale, rzp, out, codes_out, R, C, n_bits, (hipStream_t)stream);
+    miq_set_error("miq_colquant_fwd: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int64_t C, int dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(x && idx && out && R > 0 && C > 0 && C < (1ll << 31), "miq_gather_lastdim: null pointer or bad shape");
+    if (dtype == MIQ_F32) return launch_gather<float>(x, idx, out, R, C, (hipStream_t)stream);
+    if (dtype == MIQ_F16) return launch_gather<__half>(x, idx, out, R, C, (hipStream_t)stream);
+    miq_set_error("miq_gather_lastdim: unsupported dtype %d", dtype);
+    return -22;
+}

@@ -1,0 +1,270 @@
+// Backward of the static activation quantizer (what autograd derives for
+// UniformAffineQuantizer.calibration + fake_quant, reference quantize/quantizer.py:157-238,99-121).
+//
+// With per-channel scale s[c], zero point z[c], m = [0 <= round(x/s)+z <= qmax], xd = clamp(..) - z:
+//   direct path      dx  = (g*s)*m/s
+//   scale path       dS_k = sum over the cluster slab of g*(xd - m*x/s)   (0 when the scale clamp is active)
+//                    d_kmax = dS_k/qmax, d_kmin = -dS_k/qmax
+//   routing          the cluster max is an amax over channels of the per-channel amax over rows;
+//                    autograd splits evenly among tied channels, then evenly among tied rows:
+//                    every element equal to its channel max, in a channel whose max equals the
+//                    cluster max, receives (d_kmax / #tied channels) / #tied rows (same for min).
+// Three kernels: k_colbwd_stats (reads x, g), k_colbwd_shares (tiny), k_colbwd_apply (reads x, g,
+// writes dx).  In eval mode (frozen scales) only the last one runs, without shares.
+#include "miq_common.h"
+
+namespace miq {
+
+template <typename T>
+__device__ __forceinline__ void fq_terms(float xv, float s, float z, float qmax, float& q, bool& m, float& xd) {
+    q = rnd<T>(xv / s);
+    const float rr = rintf(q);
+    const float xi = rnd<T>(rnd<T>(rnd<T>(rr - q) + q) + z);
+    m = (xi >= 0.f) && (xi <= qmax);
+    xd = rnd<T>(clampf(xi, 0.f, qmax) - z);
+}
+
+// partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ scale,
+               const T* __restrict__ rzp, const float* __restrict__ chan_min, const float* __restrict__ chan_max,
+               float* __restrict__ part, long long R, int C, int rows_per_chunk, float qmax) {
+    __shared__ float sm[3][4][64 * VEC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    const bool valid = col0 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float acc[3][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = acc[2][e] = 0.f;
+    if (valid) {
+        float s[VEC], z[VEC], cmn[VEC], cmx[VEC];
+        Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            s[e] = to_f<T>(ps.e[e]);
+            z[e] = to_f<T>(pz.e[e]);
+            cmn[e] = chan_min[col0 + e];
+            cmx[e] = chan_max[col0 + e];
+        }
+        auto body = [&](const Pack<T, VEC>& a, const Pack<T, VEC>& b) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
+                float q, xd;
+                bool m;
+                fq_terms<T>(xv, s[e], z[e], qmax, q, m, xd);
+                acc[0][e] += gv * (xd - (m ? q : 0.f));
+                acc[1][e] += (xv == cmx[e]) ? 1.f : 0.f;
+                acc[2][e] += (xv == cmn[e]) ? 1.f : 0.f;
+            }
+        };
+        long long r = r0 + w;
+        for (; r + 4 < r1; r += 8) {
+            Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
+            Pack<T, VEC> a1 = ld_pack<T, VEC>(x + (r + 4) * C + col0), b1 = ld_pack<T, VEC>(g + (r + 4) * C + col0);
+            body(a0, b0);
+            body(a1, b1);
+        }
+        for (; r < r1; r += 4) {
+            Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
+            body(a0, b0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sm[k][w][lane * VEC + e] = acc[k][e];
+    __syncthreads();
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int i = lane * VEC + e;
+                part[((long long)k * gridDim.y + blockIdx.y) * C + col0 + e] =
+                    (sm[k][0][i] + sm[k][1][i]) + (sm[k][2][i] + sm[k][3][i]);
+            }
+    }
+}
+
+// fold the row-chunk partials into chunk 0 (one thread per channel; a thread only touches its own column)
+__global__ void __launch_bounds__(256) k_colbwd_fold(float* __restrict__ part, int nchunk, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = 0.f;
+        for (int j = 0; j < nchunk; ++j) v += part[((long long)k * nchunk + j) * C + c];
+        part[((long long)k * nchunk) * C + c] = v;
+    }
+}
+
+// one block per cluster (+1 for un-clustered channels): per-channel shares for the max / min elements
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_colbwd_shares(const float* __restrict__ part, int nchunk, int C, const float* __restrict__ chan_min,
+                const float* __restrict__ chan_max, const T* __restrict__ kmin, const T* __restrict__ kmax,
+                const int* __restrict__ starts, int ncl, float qmax, float* __restrict__ share_min,
+                float* __restrict__ share_max) {
+    __shared__ float lds[48];
+    const int k = blockIdx.x;
+    const bool own = k >= ncl;
+    const int st = own ? starts[ncl] : starts[k];
+    const int en = own ? C : starts[k + 1];
+    const float lo = rnd<T>(kClipLo);
+    auto colsum = [&](int which, int c) { return part[((long long)which * nchunk) * C + c]; };  // folded
+    if (own) {
+        for (int c = st + threadIdx.x; c < en; c += 256) {
+            const float mn = to_f<T>(kmin[c]), mx = to_f<T>(kmax[c]);
+            const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
+            const bool live = s_raw >= lo && s_raw <= kClipHi;
+            const float d = live ? colsum(0, c) / qmax : 0.f;
+            share_max[c] = d / colsum(1, c);
+            share_min[c] = -d / colsum(2, c);
+        }
+        return;
+    }
+    // cluster totals: dS, number of channels attaining the cluster max / min
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int c = st + threadIdx.x; c < en; c += 256) {
+        acc[0] += colsum(0, c);
+        acc[1] += (chan_max[c] == to_f<T>(kmax[c])) ? 1.f : 0.f;
+        acc[2] += (chan_min[c] == to_f<T>(kmin[c])) ? 1.f : 0.f;
+    }
+    team_sum<256, 3>(acc, lds);
+    if (en <= st) return;
+    const float mn = to_f<T>(kmin[st]), mx = to_f<T>(kmax[st]);
+    const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
+    const bool live = s_raw >= lo && s_raw <= kClipHi;
+    const float d = live ? acc[0] / qmax : 0.f;
+    for (int c = st + threadIdx.x; c < en; c += 256) {
+        share_max[c] = (chan_max[c] == mx) ? (d / acc[1]) / colsum(1, c) : 0.f;
+        share_min[c] = (chan_min[c] == mn) ? (-d / acc[2]) / colsum(2, c) : 0.f;
+    }
+}
+
+template <typename T, int VEC, bool ROUTE>
+__global__ void __launch_bounds__(256)
+k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ scale,
+               const T* __restrict__ rzp, const float* __restrict__ chan_min, const float* __restrict__ chan_max,
+               const float* __restrict__ share_min, const float* __restrict__ share_max, T* __restrict__ dx,
+               long long R, int C, int rows_per_chunk, float qmax) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    if (col0 >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float s[VEC], z[VEC], cmn[VEC], cmx[VEC], hmn[VEC], hmx[VEC];
+    Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        s[e] = to_f<T>(ps.e[e]);
+        z[e] = to_f<T>(pz.e[e]);
+        if (ROUTE) {
+            cmn[e] = chan_min[col0 + e];
+            cmx[e] = chan_max[col0 + e];
+            hmn[e] = share_min[col0 + e];
+            hmx[e] = share_max[col0 + e];
+        }
+    }
+    auto body = [&](const Pack<T, VEC>& a, const Pack<T, VEC>& b, long long r) {
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
+            float q, xd;
+            bool m;
+            fq_terms<T>(xv, s[e], z[e], qmax, q, m, xd);
+            float d = m ? (gv * s[e]) / s[e] : 0.f;
+            if (ROUTE) {
+                if (xv == cmx[e]) d += hmx[e];
+                if (xv == cmn[e]) d += hmn[e];
+            }
+            o.e[e] = from_f<T>(d);
+        }
+        st_pack<T, VEC>(dx + r * C + col0, o);
+    };
+    long long r = r0 + w;
+    for (; r + 4 < r1; r += 8) {
+        Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
+        Pack<T, VEC> a1 = ld_pack<T, VEC>(x + (r + 4) * C + col0), b1 = ld_pack<T, VEC>(g + (r + 4) * C + col0);
+        body(a0, b0, r);
+        body(a1, b1, r + 4);
+    }
+    for (; r < r1; r += 4) {
+        Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
+        body(a0, b0, r);
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+static int colquant_bwd_t(const void* g, const void* x, const void* scale, const void* rzp, const float* chan_min,
+                          const float* chan_max, const void* kmin, const void* kmax, const int* starts, int ncl,
+                          long long covered, float* ws, int nchunk, void* dx, long long R, long long C, int n_bits,
+                          hipStream_t stream) {
+    constexpr int N = VecOf<T>::N;
+    const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(scale) && aligned16(rzp);
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int tiles = (int)(vec_ok ? (C / N + 63) / 64 : (C + 63) / 64);
+    const int rpc = (int)((R + nchunk - 1) / nchunk);
+    const bool route = chan_min != nullptr;
+    float* part = ws;                                    // [3, nchunk, C]
+    float* share_min = ws + 3ll * nchunk * C;            // [C]
+    float* share_max = share_min + C;                    // [C]
+    if (route) {
+        if (vec_ok)
+            hipLaunchKernelGGL((k_colbwd_stats<T, N>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
+                               (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
+        else
+            hipLaunchKernelGGL((k_colbwd_stats<T, 1>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
+                               (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
+        const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
+        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, part, nchunk, (int)C);
+        hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(grid), dim3(256), 0, stream, part, nchunk, (int)C, chan_min, chan_max,
+                           (const T*)kmin, (const T*)kmax, starts, ncl, qmax, share_min, share_max);
+    }
+#define APPLY(VECN, RT)                                                                                               \
+    hipLaunchKernelGGL((k_colbwd_apply<T, VECN, RT>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x,         \
+                       (const T*)g, (const T*)scale, (const T*)rzp, chan_min, chan_max, share_min, share_max, (T*)dx, \
+                       R, (int)C, rpc, qmax)
+    if (vec_ok) {
+        if (route) APPLY(N, true); else APPLY(N, false);
+    } else {
+        if (route) APPLY(1, true); else APPLY(1, false);
+    }
+#undef APPLY
+    MIQ_CHECK_LAUNCH("miq_colquant_bwd");
+    return 0;
+}
+
+}  // namespace miq
+
+using namespace miq;
+
+extern "C" int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, const void* rzp,
+                                const float* chan_min, const float* chan_max, const void* kmin, const void* kmax,
+                                const int* starts, int n_clusters, int64_t covered, float* workspace, int nchunk,
+                                void* dx, int64_t R, int64_t C, int n_bits, int dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(grad_out && x && scale && rzp && dx && R > 0 && C > 0 && C < (1ll << 31),
+                  "miq_colquant_bwd: null pointer or bad shape");
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && nchunk >= 1, "miq_colquant_bwd: bad n_bits/nchunk");
+    MIQ_CHECK_ARG((chan_min == nullptr) == (chan_max == nullptr), "miq_colquant_bwd: chan_min/chan_max must come together");
+    MIQ_CHECK_ARG(!chan_min || (kmin && kmax && starts && workspace && covered >= 0 && covered <= C),
+                  "miq_colquant_bwd: routing needs kmin, kmax, starts and a workspace");
+    if (dtype == MIQ_F32)
+        return colquant_bwd_t<float>(grad_out, x, scale, rzp, chan_min, chan_max, kmin, kmax, starts, n_clusters, covered,
+                                     workspace, nchunk, dx, R, C, n_bits, (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return colquant_bwd_t<__half>(grad_out, x, scale, rzp, chan_min, chan_max, kmin, kmax, starts, n_clusters, covered,
+                                      workspace, nchunk, dx, R, C, n_bits, (hipStream_t)stream);
+    miq_set_error("miq_colquant_bwd: unsupported dtype %d", dtype);
+    return -22;
+}

@@ -97,3 +97,176 @@ class UniformRowFQ(torch.autograd.Function):
         dx, d_up, d_low = rowquant_uniform_bwd(g.contiguous(), x, n_bits, symmetric, up, low, group, row_bits,
                                                clamp_asym, want_dx=need_dx)
         return dx, d_up, d_low, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# static activation quantisation over the last axis
+# ---------------------------------------------------------------------------------------------
+class ClusterLayout:
+    """Contiguous channel clusters of a C-channel axis: device prefix sums + bookkeeping.
+
+    ``counts`` None means one cluster spanning all channels (per-tensor statistics).
+    Channels beyond sum(counts) belong to no cluster and keep per-channel statistics
+    (quantize/quantizer.py:201-210 only visits the listed clusters).
+    """
+
+    _cache = {}
+
+    def __init__(self, counts, C: int, device):
+        if counts is None:
+            counts = [C]
+        counts = [int(c) for c in counts]
+        if any(c < 0 for c in counts) or sum(counts) > C:
+            raise L.MiqError(f"cluster sizes {counts[:4]}... do not fit {C} channels")
+        starts = [0]
+        for c in counts:
+            starts.append(starts[-1] + c)
+        self.n_clusters = len(counts)
+        self.covered = starts[-1]
+        self.C = C
+        self.starts = torch.tensor(starts, dtype=torch.int32, device=device)
+
+    @classmethod
+    def get(cls, counts, C: int, device):
+        key = (None if counts is None else tuple(int(c) for c in counts), int(C), str(device))
+        hit = cls._cache.get(key)
+        if hit is None:
+            if len(cls._cache) > 256:
+                cls._cache.clear()
+            hit = cls._cache[key] = cls(counts, C, device)
+        return hit
+
+
+def colstat_chunks(R: int, C: int, dtype) -> int:
+    return int(L.lib().miq_colstat_chunks(L.i64(R), L.i64(C), L.i32(L._DT[dtype])))
+
+
+def act_calibrate(x2d, n_bits: int, metric: str, layout: ClusterLayout, cached_min=None, cached_max=None, idx=None):
+    """Statistics pass + cluster merge + scale.  x2d is [R, C] contiguous.
+
+    Returns dict(scale, zp, rzp, cmin, cmax: [C] in x's dtype; chan_min, chan_max: [C] float32
+    per-channel statistics before the cluster merge, needed by the backward pass).
+    """
+    dev = L.check_gpu(x2d, cached_min, cached_max, idx)
+    R, C = x2d.shape
+    nchunk = colstat_chunks(R, C, x2d.dtype)
+    part = torch.empty((2, nchunk + 1, C), dtype=torch.float32, device=dev)
+    outs = torch.empty((5, C), dtype=x2d.dtype, device=dev)
+    if idx is not None and idx.dtype != torch.int32:
+        raise L.MiqError("reorder index must be int32 on the device")
+    code = L.dtype_code(x2d)
+    st = L.stream_of(x2d)
+    with torch.cuda.device(dev):
+        L.call("miq_colstat_minmax", L.ptr(x2d), L.i64(R), L.i64(C), L.ptr(part[0]), L.ptr(part[1]), L.i32(nchunk),
+               L.i32(code), st)
+        L.call("miq_cluster_scale", L.ptr(part[0]), L.ptr(part[1]), L.i32(nchunk), L.i64(C), L.ptr(idx),
+               L.ptr(cached_min), L.ptr(cached_max), L.i32(1 if metric == "ema_minmax" else 0), L.ptr(layout.starts),
+               L.i32(layout.n_clusters), L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(outs[0]), L.ptr(outs[1]),
+               L.ptr(outs[2]), L.ptr(outs[3]), L.ptr(outs[4]), L.i32(code), st)
+    return {"cmin": outs[0], "cmax": outs[1], "scale": outs[2], "zp": outs[3], "rzp": outs[4],
+            "chan_min": part[0, nchunk], "chan_max": part[1, nchunk]}
+
+
+def colquant_fwd(x2d, scale, rzp, n_bits: int, want_codes: bool = False):
+    dev = L.check_gpu(x2d, scale, rzp)
+    R, C = x2d.shape
+    out = torch.empty_like(x2d)
+    codes = torch.empty((R, C), dtype=torch.uint8, device=dev) if want_codes else None
+    with torch.cuda.device(dev):
+        L.call("miq_colquant_fwd", L.ptr(x2d), L.ptr(scale), L.ptr(rzp), L.ptr(out), L.ptr(codes), L.i64(R), L.i64(C),
+               L.i32(int(n_bits)), L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
+    return out, codes
+
+
+def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None):
+    """route = (chan_min, chan_max, kmin, kmax, layout) enables the min/max routing (calibration mode)."""
+    dev = L.check_gpu(g2d, x2d, scale, rzp)
+    R, C = x2d.shape
+    dx = torch.empty_like(x2d)
+    nchunk = colstat_chunks(R, C, x2d.dtype)
+    if route is not None:
+        chan_min, chan_max, kmin, kmax, layout = route
+        ws = torch.empty((3 * nchunk + 2) * C, dtype=torch.float32, device=dev)
+        args = (L.ptr(chan_min), L.ptr(chan_max), L.ptr(kmin), L.ptr(kmax), L.ptr(layout.starts),
+                L.i32(layout.n_clusters), L.i64(layout.covered), L.ptr(ws))
+    else:
+        args = (L.ptr(None),) * 5 + (L.i32(0), L.i64(0), L.ptr(None))
+    with torch.cuda.device(dev):
+        L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, L.i32(nchunk), L.ptr(dx),
+               L.i64(R), L.i64(C), L.i32(int(n_bits)), L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
+    return dx
+
+
+def gather_lastdim(x, idx_i32):
+    """out[..., c] = x[..., idx[c]] (torch.index_select along the last axis), idx int32 on the device."""
+    dev = L.check_gpu(x, idx_i32)
+    C = x.shape[-1]
+    if idx_i32.dtype != torch.int32 or idx_i32.numel() != C:
+        raise L.MiqError("gather index must be an int32 tensor with one entry per channel")
+    R = x.numel() // C if C else 0
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        L.call("miq_gather_lastdim", L.ptr(x), L.ptr(idx_i32), L.ptr(out), L.i64(R), L.i64(C), L.i32(L.dtype_code(x)),
+               L.stream_of(x))
+    return out
+
+
+class GatherLastDim(torch.autograd.Function):
+    """index_select along the last axis by a permutation; the backward is the gather by the inverse."""
+
+    @staticmethod
+    def forward(ctx, x, idx_i32, inv_i32):
+        ctx.save_for_backward(inv_i32)
+        return gather_lastdim(x.contiguous(), idx_i32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return gather_lastdim(g.contiguous(), inv), None, None
+
+
+class ActEvalFQ(torch.autograd.Function):
+    """Frozen per-channel scales: out = fq(x); dx = g * [level inside the grid]."""
+
+    @staticmethod
+    def forward(ctx, x, scale_vec, rzp_vec, n_bits):
+        x = x.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        out, _ = colquant_fwd(x2, scale_vec, rzp_vec, n_bits)
+        ctx.save_for_backward(x2, scale_vec, rzp_vec)
+        ctx.n_bits = n_bits
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, s, z = ctx.saved_tensors
+        dx = colquant_bwd(g.contiguous().reshape(x2.shape), x2, s, z, ctx.n_bits)
+        return dx.reshape(g.shape), None, None, None
+
+
+class ActCalibFQ(torch.autograd.Function):
+    """Calibration-mode forward with freshly computed statistics (no cached values): the scale is a
+    function of x, so the backward routes the scale gradient to the extreme elements."""
+
+    @staticmethod
+    def forward(ctx, x, n_bits, metric, layout, cached_min, cached_max, holder):
+        x = x.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max)
+        out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
+        holder.update(st)
+        ctx.fresh = cached_min is None
+        ctx.layout = layout
+        ctx.n_bits = n_bits
+        ctx.save_for_backward(x2, st["scale"], st["rzp"], st["chan_min"], st["chan_max"], st["cmin"], st["cmax"])
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, s, z, chan_min, chan_max, kmin, kmax = ctx.saved_tensors
+        if not ctx.fresh:
+            raise L.MiqError("backward through cached activation statistics is not defined: call free() on the "
+                             "quantizer after every optimizer step (the calibration loop does)")
+        dx = colquant_bwd(g.contiguous().reshape(x2.shape), x2, s, z, ctx.n_bits,
+                          route=(chan_min, chan_max, kmin, kmax, ctx.layout))
+        return dx.reshape(g.shape), None, None, None, None, None, None

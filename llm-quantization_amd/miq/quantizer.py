@@ -1,0 +1,244 @@
+"""UniformAffineQuantizer: same constructor, attributes and methods as the reference class
+(quantize/quantizer.py:21-283), with the arithmetic done by libmiq's fused HIP kernels.
+
+Two regimes, as in the reference:
+  * ``dynamic=True`` (weights; activations with --a_dynamic): row-wise min/max over the last axis,
+    optional learnable weight clipping, one fused kernel (forward) + one (backward);
+  * ``dynamic=False`` (static activations): calibration mode accumulates per-tensor or per-cluster
+    statistics (running min/max or EMA) AND quantizes; eval mode quantizes with the frozen buffers.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from ._lib import MiqError
+
+CLIPMIN = 1e-5
+
+
+def round_ste(x: torch.Tensor):
+    """Round with a straight-through gradient (kept for API compatibility)."""
+    return (x.round() - x).detach() + x
+
+
+class UniformAffineQuantizer(nn.Module):
+    def __init__(
+        self,
+        n_bits: int = 8,
+        symmetric: bool = False,
+        per_channel_axes=[],
+        metric="minmax",
+        dynamic=False,
+        dynamic_method="per_cluster",
+        group_size=None,
+        shape=None,
+        lwc=False,
+        target_bit=0,
+    ):
+        super().__init__()
+        self.symmetric = symmetric
+        assert 2 <= n_bits <= 16, "bitwidth not supported"
+        self.n_bits = n_bits
+        self.qmin = 0
+        self.qmax = 2 ** (n_bits) - 1
+        self.per_channel_axes = per_channel_axes
+        self.metric = metric
+        self.cluster_counts = None
+        self.cluster_dim = None
+
+        self.scale = None
+        self.zero_point = None
+        self.round_zero_point = None
+
+        self.cached_xmin = None
+        self.cached_xmax = None
+        self.dynamic = dynamic
+        self.dynamic_method = dynamic_method
+        self.deficiency = 0
+        self.lwc = lwc
+        self.mode = "calibration"
+
+        init_value = 4.0  # sigmoid(4) = 0.982: start almost un-clipped
+        if lwc:
+            if group_size:
+                dim1 = int(shape[0] * math.ceil(shape[1] / group_size))
+                self.deficiency = shape[-1] % group_size
+                if self.deficiency > 0:
+                    self.deficiency = group_size - self.deficiency
+                    assert self.symmetric  # zero padding is only meaningful for symmetric grids
+            else:
+                dim1 = shape[0]
+            self.upbound_factor = nn.Parameter(torch.ones((dim1, 1)) * init_value)
+            self.lowbound_factor = nn.Parameter(torch.ones((dim1, 1)) * init_value)
+        self.sigmoid = nn.Sigmoid()
+
+        self.enable = True
+        self.group_size = group_size
+        self._vec = None  # per-channel [C] copies of (scale, rzp) for the kernels
+
+    # ------------------------------------------------------------------ small API surface
+    def change_n_bits(self, n_bits):
+        self.n_bits = n_bits
+        self.qmin = 0
+        self.qmax = 2 ** (n_bits) - 1
+
+    def set_calibration_mode(self):
+        self.mode = "calibration"
+
+    def set_eval_mode(self):
+        self.mode = "eval"
+
+    def free(self):
+        self.cached_xmax = None
+        self.cached_xmin = None
+
+    def register_scales_and_zeros(self):
+        self.register_buffer("scales", self.scale)
+        self.register_buffer("zeros", self.round_zero_point)
+        del self.scale
+        del self.round_zero_point
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor):
+        if self.n_bits >= 16 or not self.enable:
+            return x
+        if self.metric == "fix0to1":
+            # unreachable in the reference's flows (its only user is built with n_bits=16)
+            return x.mul_(2 ** self.n_bits - 1).round_().div_(2 ** self.n_bits - 1)
+        if self.dynamic:
+            if self.dynamic_method in ("per_token", "per_channel"):
+                return self._row_dynamic(x)
+            raise MiqError(f"dynamic quantization with dynamic_method={self.dynamic_method!r} has no scale rule "
+                           "(the reference leaves scale unset in this configuration)")
+        if self.mode == "calibration":
+            return self._static_calibrate_and_quant(x)
+        return self._static_eval(x)
+
+    # ------------------------------------------------------------------ dynamic, row-wise
+    def _lwc_params(self, x):
+        if not self.lwc:
+            return None, None
+        up, low = self.upbound_factor, self.lowbound_factor
+        if up.dtype != x.dtype:
+            raise MiqError(f"LWC factors are {up.dtype} but the tensor is {x.dtype}: call .half()/.float() on the module")
+        return up, low
+
+    def _row_dynamic(self, x):
+        up, low = self._lwc_params(x)
+        if self.group_size:
+            assert x.dim() == 2, "only support linear layer now"
+        out, scale, rzp = F.UniformRowFQ.apply(x, up, low, self.n_bits, bool(self.symmetric), int(self.group_size or 0),
+                                               None, False)
+        if not self.group_size and x.dim() != 2:
+            scale = scale.reshape(*x.shape[:-1], 1)
+            rzp = rzp.reshape(*x.shape[:-1], 1)
+        self.scale = scale
+        self.round_zero_point = rzp
+        return out
+
+    def per_token_dynamic_calibration(self, x):
+        """Sets ``scale`` / ``round_zero_point`` from x (reference quantizer.py:248-273)."""
+        with torch.no_grad():
+            self._row_dynamic(x)
+
+    # ------------------------------------------------------------------ static activations
+    def _layout(self, x):
+        C = x.shape[-1]
+        if self.dynamic_method == "per_tensor" or self.cluster_dim is None:
+            counts, kind = None, "tensor"
+        else:
+            if self.cluster_dim != x.dim() - 1:
+                raise MiqError(f"cluster_dim={self.cluster_dim} must be the last axis of a {x.dim()}-D activation")
+            counts, kind = self.cluster_counts, "cluster"
+        return F.ClusterLayout.get(counts, C, x.device), kind
+
+    def _stat_shape(self, x, kind):
+        if self.dynamic_method == "per_tensor":
+            return ()
+        if kind == "tensor":  # per_cluster without a cluster axis: every axis reduced, keepdim
+            return (1,) * x.dim()
+        return (1,) * (x.dim() - 1) + (x.shape[-1],)
+
+    def _publish(self, x, st, kind):
+        shape = self._stat_shape(x, kind)
+        pick = (lambda v: v[0].reshape(shape)) if kind == "tensor" else (lambda v: v.reshape(shape))
+        for name in ("scale", "zero_point", "round_zero_point"):
+            if name in self._buffers:
+                del self._buffers[name]
+            elif hasattr(self, name):
+                delattr(self, name)
+        self.register_buffer("scale", pick(st["scale"]))
+        self.register_buffer("zero_point", pick(st["zp"]))
+        self.register_buffer("round_zero_point", pick(st["rzp"]))
+        self.cached_xmin = pick(st["cmin"])
+        self.cached_xmax = pick(st["cmax"])
+        self._vec = (st["scale"], st["rzp"], st["cmin"], st["cmax"])
+
+    def _cached_vectors(self, x):
+        """[C] vectors of the cached statistics (or None, None)."""
+        if self.cached_xmax is None:
+            return None, None
+        C = x.shape[-1]
+        if self._vec is not None and self._vec[2].dtype == x.dtype and self._vec[2].numel() == C:
+            return self._vec[2], self._vec[3]
+        cm, cx = self.cached_xmin.to(x.dtype), self.cached_xmax.to(x.dtype)
+        return cm.reshape(-1).expand(C).contiguous(), cx.reshape(-1).expand(C).contiguous()
+
+    def _static_calibrate_and_quant(self, x):
+        if self.symmetric:
+            raise MiqError("static activation quantization is asymmetric only (the reference has no symmetric rule)")
+        if self.dynamic_method not in ("per_tensor", "per_cluster"):
+            raise MiqError(f"unknown dynamic_method {self.dynamic_method!r}")
+        layout, kind = self._layout(x)
+        cmin, cmax = self._cached_vectors(x)
+        holder = {}
+        out = F.ActCalibFQ.apply(x, self.n_bits, self.metric, layout, cmin, cmax, holder)
+        self._publish(x, holder, kind)
+        return out
+
+    def calibration(self, x: torch.Tensor):
+        """Statistics update only (reference quantizer.py:157-168)."""
+        layout, kind = self._layout(x)
+        cmin, cmax = self._cached_vectors(x)
+        xc = x.detach().contiguous()
+        st = F.act_calibrate(xc.reshape(-1, x.shape[-1]), self.n_bits, self.metric, layout, cmin, cmax)
+        self._publish(x, st, kind)
+
+    def _eval_vectors(self, x):
+        C = x.shape[-1]
+        v = self._vec
+        if v is not None and v[0].dtype == x.dtype and v[0].numel() == C and v[0].device == x.device:
+            return v[0], v[1]
+        scale = self.scale if self.scale is not None else getattr(self, "scales", None)
+        rzp = self.round_zero_point if self.round_zero_point is not None else getattr(self, "zeros", None)
+        if scale is None or rzp is None:
+            raise MiqError("eval-mode activation quantizer has no calibrated scale")
+        s = scale.to(device=x.device, dtype=x.dtype).reshape(-1).expand(C).contiguous()
+        z = rzp.to(device=x.device, dtype=x.dtype).reshape(-1).expand(C).contiguous()
+        self._vec = (s, z, s, z)
+        return s, z
+
+    def _static_eval(self, x):
+        s, z = self._eval_vectors(x)
+        return F.ActEvalFQ.apply(x, s, z, self.n_bits)
+
+    def fake_quant(self, x, scale, round_zero_point):
+        """Quantize-dequantize with given parameters: per-channel ([..., C] / scalar) layouts only."""
+        C = x.shape[-1]
+        if scale.numel() not in (1, C):
+            raise MiqError("fake_quant with explicit parameters supports scalar or per-last-axis-channel scales")
+        s = scale.to(x.dtype).reshape(-1).expand(C).contiguous()
+        z = round_zero_point.to(x.dtype).reshape(-1).expand(C).contiguous()
+        return F.ActEvalFQ.apply(x, s, z, self.n_bits)
+
+    def _apply(self, fn, *a, **k):
+        # .half()/.float()/.to(): drop the private kernel-side copies, they are rebuilt lazily
+        self._vec = None
+        if self.cached_xmin is not None:
+            self.cached_xmin = fn(self.cached_xmin)
+            self.cached_xmax = fn(self.cached_xmax)
+        return super()._apply(fn, *a, **k)
