@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Headline benchmark: the fake-quantization hot path of one OmniQuant calibration step on a
+Llama-2-7B-shaped block (BASELINE.json configs[1]: W4A4, static per-cluster activation quantization
+with RPTQ channel reorder), synthetic data, one MI355X per rank.
+
+One "step" = everything the quantizer kernels do for ONE calibration sample of 2048 tokens
+(GEMMs / attention / layer norms are not part of this path and are not executed):
+  forward   7 weight matrices row-wise W4 fake-quant with learnable clipping (fp32)
+            2 reorder gathers of the residual stream (fp16, [1,2048,4096])
+            10 activation sites: per-cluster EMA min/max calibration + A4 quantization
+              q/k/v inputs   3 x [1,2048,4096] fp32 (layer-norm output), 32 clusters x 128 channels
+              q, k, v, o-in  4 x [1,2048,4096] fp16, 128 clusters x 32 channels (4 per head)
+              gate/up inputs 2 x [2048,4096]   fp32, 32 clusters x 128
+              down input     1 x [2048,11008]  fp16, 32 clusters x 344
+  backward  straight-through gradients of all of the above (input gradients included, as with
+            LET enabled) and, with N > 1 ranks, one RCCL all-reduce of the packed LWC gradients
+            (84,992 floats) — the data-parallel exchange of the calibration loop.
+
+value = algorithmic bytes of the step (read-once/write-once accounting: fwd 2ns, bwd 3ns, calibrate+
+quantize 3ns, gather 2ns) summed over all ranks / wall time of the slowest rank.  Inputs are resident
+in HBM before the timed region.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]    (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "llm-quantization_amd"))
+sys.path.insert(0, REPO)
+
+from miq import functional as F  # noqa: E402
+from miq import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+T = 2048
+H, FF, HEADS = 4096, 11008, 32
+WEIGHTS = [("q", H, H), ("k", H, H), ("v", H, H), ("o", H, H), ("gate", FF, H), ("up", FF, H), ("down", H, FF)]
+F32, F16 = torch.float32, torch.float16
+SITES = [  # name, shape, dtype, cluster sizes
+    ("q_in", (1, T, H), F32, [H // 32] * 32), ("k_in", (1, T, H), F32, [H // 32] * 32),
+    ("v_in", (1, T, H), F32, [H // 32] * 32),
+    ("q_out", (1, T, H), F16, [H // HEADS // 4] * (4 * HEADS)), ("k_out", (1, T, H), F16, [H // HEADS // 4] * (4 * HEADS)),
+    ("v_out", (1, T, H), F16, [H // HEADS // 4] * (4 * HEADS)), ("o_in", (1, T, H), F16, [H // HEADS // 4] * (4 * HEADS)),
+    ("gate_in", (T, H), F32, [H // 32] * 32), ("up_in", (T, H), F32, [H // 32] * 32),
+    ("down_in", (T, FF), F16, [FF // 32] * 32),
+]
+W_BITS, A_BITS = 4, 4
+
+
+class Segments:
+    """HIP-event brackets around kernel families, recorded on the stream the kernels run on."""
+
+    def __init__(self):
+        self.ev = {}
+
+    def run(self, name, fn, timed):
+        if not timed:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.ev.setdefault(name, []).append((a, b))
+        return r
+
+    def totals_ms(self):
+        return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.ev.items()}
+
+
+class Workload:
+    def __init__(self, dev, seed):
+        self.dev = dev
+        self.w, self.gw, self.up, self.low = [], [], [], []
+        for i, (_n, o, c) in enumerate(WEIGHTS):
+            self.w.append(synth.weight(o, c, seed + i).to(dev))
+            self.gw.append((synth.grad_like(self.w[-1].cpu(), seed + 50 + i) * 1e-3).to(dev))
+            u, l = synth.lwc_factors(o, seed + 100 + i)
+            self.up.append(u.to(dev))
+            self.low.append(l.to(dev))
+        self.x, self.gx, self.layout = [], [], []
+        for i, (_n, shape, dt, counts) in enumerate(SITES):
+            a = synth.activation(shape, seed + 200 + i, dt)
+            self.x.append(a.to(dev))
+            self.gx.append((synth.grad_like(a, seed + 300 + i) * 1e-3).to(dev))
+            self.layout.append(F.ClusterLayout.get(counts, shape[-1], torch.device(dev)))
+        self.res = [synth.activation((1, T, H), seed + 400 + i, F16).to(dev) for i in range(2)]
+        self.gres = [torch.randn_like(r) for r in self.res]
+        self.idx = [synth.permutation(H, seed + 500 + i).to(torch.int32).to(dev) for i in range(2)]
+        self.inv = [torch.argsort(i.long()).to(torch.int32) for i in self.idx]
+        self.n_lwc = sum(2 * o for _n, o, _c in WEIGHTS)
+        self.flat = torch.empty(self.n_lwc, dtype=torch.float32, device=dev)
+
+    # algorithmic bytes per family and launches per step
+    def bytes(self):
+        wb = sum(o * c * 4 for _n, o, c in WEIGHTS)
+        ab = sum(x.numel() * x.element_size() for x in self.x)
+        gb = sum(r.numel() * r.element_size() for r in self.res)
+        return {"rowquant_fwd": 2 * wb, "rowquant_bwd": 3 * wb, "act_calib_quant_fwd": 3 * ab, "act_bwd": 3 * ab,
+                "gather_fwd": 2 * gb, "gather_bwd": 2 * gb}
+
+    def launches(self):
+        return {"rowquant_fwd": len(WEIGHTS), "rowquant_bwd": len(WEIGHTS), "act_calib_quant_fwd": len(SITES),
+                "act_bwd": len(SITES), "gather_fwd": 2, "gather_bwd": 2}
+
+    def families(self):
+        """Ordered (name, callable) pairs; every callable only enqueues kernels on the current stream."""
+        saved, grads = [], []
+
+        def w_fwd():
+            for i in range(len(WEIGHTS)):
+                F.rowquant_uniform_fwd(self.w[i], W_BITS, False, self.up[i], self.low[i])
+
+        def g_fwd():
+            for i in range(2):
+                F.gather_lastdim(self.res[i], self.idx[i])
+
+        def a_fwd():
+            saved.clear()
+            for i, (_n, shape, _dt, _c) in enumerate(SITES):
+                x2 = self.x[i].reshape(-1, shape[-1])
+                st = F.act_calibrate(x2, A_BITS, "ema_minmax", self.layout[i])
+                F.colquant_fwd(x2, st["scale"], st["rzp"], A_BITS)
+                saved.append(st)
+
+        def a_bwd():
+            for i, (_n, shape, _dt, _c) in enumerate(SITES):
+                x2 = self.x[i].reshape(-1, shape[-1])
+                st = saved[i]
+                F.colquant_bwd(self.gx[i].reshape(x2.shape), x2, st["scale"], st["rzp"], A_BITS,
+                               route=(st["chan_min"], st["chan_max"], st["cmin"], st["cmax"], self.layout[i]))
+
+        def g_bwd():
+            for i in range(2):
+                F.gather_lastdim(self.gres[i], self.inv[i])
+
+        def w_bwd():
+            grads.clear()
+            for i in range(len(WEIGHTS)):
+                _dx, du, dl = F.rowquant_uniform_bwd(self.gw[i], self.w[i], W_BITS, False, self.up[i], self.low[i])
+                grads.extend((du, dl))
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+
+        return [("rowquant_fwd", w_fwd), ("gather_fwd", g_fwd), ("act_calib_quant_fwd", a_fwd), ("act_bwd", a_bwd),
+                ("gather_bwd", g_bwd), ("rowquant_bwd", w_bwd)]
+
+    def capture(self):
+        """Capture every family into a HIP graph (removes the Python/launch overhead of ~90 small
+        launches per step; the kernels neither allocate nor synchronise, so they are capturable)."""
+        fams = self.families()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for _n, fn in fams:
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        out = []
+        for name, fn in fams:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            out.append((name, g.replay))
+        return out
+
+    def step(self, fams, seg: Segments, timed: bool, world: int):
+        for name, fn in fams:
+            seg.run(name, fn, timed)
+        if world > 1:
+            torch.distributed.all_reduce(self.flat)
+            self.flat.div_(world)
+
+
+def cpu_baseline(threads: int):
+    """The CPU oracle (bit-checked against the reference's golden vectors) on a bounded sample of the
+    same workload: one [4096,4096] weight forward+backward and one [1,2048,4096] fp32 activation site
+    forward+backward, on the host cores of this box."""
+    from oracle import miq_oracle as O
+
+    torch.set_num_threads(threads)
+    w = synth.weight(H, H, 2)
+    up, low = synth.lwc_factors(H, 3)
+    gw = synth.grad_like(w, 4)
+    a = synth.activation((1, T, H), 5)
+    ga = synth.grad_like(a, 6)
+    counts = [H // 32] * 32
+
+    def once():
+        wr = w.clone().requires_grad_(True)
+        u, l = up.clone().requires_grad_(True), low.clone().requires_grad_(True)
+        r = O.uniform_row(wr, W_BITS, False, u, l)
+        torch.autograd.grad((r.out * gw).sum(), [wr, u, l])
+        ar = a.clone().requires_grad_(True)
+        out, _ = O.act_forward(ar, O.ActState(), A_BITS, "calibration", method="per_cluster", metric="ema_minmax",
+                               cluster_dim=2, cluster_counts=counts)
+        torch.autograd.grad((out * ga).sum(), [ar])
+
+    once()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        once()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or n >= 20:
+            break
+    nbytes = (2 + 3) * w.numel() * 4 + (3 + 3) * a.numel() * 4
+    return {"value": round(nbytes * n / dt / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{n} x (uniform W4+LWC fwd+bwd on [4096,4096] fp32 + per-cluster A4 calibrate+quantize "
+                      f"fwd+bwd on [1,2048,4096] fp32), torch CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device(dev))
+
+    wl = Workload(dev, seed=2 + 1000 * rank)
+    seg = Segments()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fams = wl.families() if args.eager else wl.capture()
+    for _ in range(args.warmup):
+        wl.step(fams, seg, False, world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(fams, seg, True, world)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        by = wl.bytes()
+        step_bytes = sum(by.values())
+        totals = seg.totals_ms()
+        fam = {k: {"GBps": round(by[k] * args.steps / (totals[k] * 1e-3) / 1e9, 1),
+                   "frac_hbm_peak": round(by[k] * args.steps / (totals[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": wl.launches()[k]}
+               for k in by}
+        dom = max(totals, key=totals.get)
+        n_launch = wl.launches()[dom] * args.steps
+        achieved = by[dom] * args.steps / (totals[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom)
+        out = {
+            "metric": "fake-quant GB/s (% HBM peak) + OmniQuant block-calib s/layer, Llama-2-7B",
+            "value": round(step_bytes * world * args.steps / dt / 1e9, 1),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Llama-2-7B block, W4A4, static per-cluster activation quant + RPTQ reorder gather, "
+                                   "one 2048-token calibration sample per rank per step: quantizer kernels fwd+bwd "
+                                   "(7 weights fp32, 10 activation sites fp32/fp16, 2 gathers)",
+                       "tokens_per_step_per_gpu": T, "w_bits": W_BITS, "a_bits": A_BITS,
+                       "launch": "eager" if args.eager else "hipGraph replay per kernel family",
+                       "parallelism": f"dp{world}" + (" + RCCL all-reduce of 84992 LWC grads" if world > 1 else "")},
+            "frac_hbm_peak": round(step_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": by[dom] // wl.launches()[dom],
+                         "avg_launch_us": round(totals[dom] * 1e3 / n_launch, 2)},
+            "families": fam,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

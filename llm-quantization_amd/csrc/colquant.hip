@@ -100,18 +100,38 @@ struct ScaleArgs {
     T* rzp;              // [C]
 };
 
-// step 1: one thread per output channel folds the row-chunk partials of its source column and
-// applies the running-min/max or EMA update against the cached statistics.
+// step 1: fold the row-chunk partials of every output channel's source column and apply the
+// running-min/max or EMA update against the cached statistics.  Block = 64 channels x 4 waves; wave w
+// folds chunks w, w+4, ... (coalesced 256-byte reads, several in flight), LDS joins the four waves.
 template <typename T>
 __global__ void __launch_bounds__(256) k_colstat_combine(ScaleArgs<T> a) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= a.C) return;
-    const int src = a.idx ? a.idx[c] : c;
+    __shared__ float smn[4][64], smx[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool valid = c < a.C;
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    for (int j = 0; j < a.nchunk; ++j) {
-        mn = nmin(mn, a.pmin[(long long)j * a.C + src]);
-        mx = nmax(mx, a.pmax[(long long)j * a.C + src]);
+    if (valid) {
+        const int src = a.idx ? a.idx[c] : c;
+        int j = w;
+        for (; j + 12 < a.nchunk; j += 16) {
+            const float a0 = a.pmin[(long long)j * a.C + src], b0 = a.pmax[(long long)j * a.C + src];
+            const float a1 = a.pmin[(long long)(j + 4) * a.C + src], b1 = a.pmax[(long long)(j + 4) * a.C + src];
+            const float a2 = a.pmin[(long long)(j + 8) * a.C + src], b2 = a.pmax[(long long)(j + 8) * a.C + src];
+            const float a3 = a.pmin[(long long)(j + 12) * a.C + src], b3 = a.pmax[(long long)(j + 12) * a.C + src];
+            mn = nmin(nmin(mn, a0), nmin(a1, nmin(a2, a3)));
+            mx = nmax(nmax(mx, b0), nmax(b1, nmax(b2, b3)));
+        }
+        for (; j < a.nchunk; j += 4) {
+            mn = nmin(mn, a.pmin[(long long)j * a.C + src]);
+            mx = nmax(mx, a.pmax[(long long)j * a.C + src]);
+        }
     }
+    smn[w][lane] = mn;
+    smx[w][lane] = mx;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    mn = nmin(nmin(smn[0][lane], smn[1][lane]), nmin(smn[2][lane], smn[3][lane]));
+    mx = nmax(nmax(smx[0][lane], smx[1][lane]), nmax(smx[2][lane], smx[3][lane]));
     if (a.cached_min) {
         const float pm = to_f<T>(a.cached_min[c]), px = to_f<T>(a.cached_max[c]);
         if (a.metric == 0) {
@@ -245,8 +265,8 @@ k_gather(const T* __restrict__ x, const int* __restrict__ idx, T* __restrict__ o
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static inline int pick_chunks(long long R, int col_tiles) {
-    // aim at ~2048 blocks, at least 16 rows per chunk
-    long long want = 2048 / (col_tiles > 0 ? col_tiles : 1);
+    // aim at ~1024 blocks (4 per CU), at least 16 rows per chunk
+    long long want = 1024 / (col_tiles > 0 ? col_tiles : 1);
     if (want < 1) want = 1;
     long long maxc = (R + 15) / 16;
     if (want > maxc) want = maxc;
@@ -352,7 +372,7 @@ static int cluster_scale_t(float* pmin, float* pmax, int nchunk, int64_t C, cons
     a.cmin_out = (T*)cmin_out; a.cmax_out = (T*)cmax_out; a.scale = (T*)scale; a.zp = (T*)zp; a.rzp = (T*)rzp;
     const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
     if (grid == 0) return 0;
-    hipLaunchKernelGGL((k_colstat_combine<T>), dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((k_colstat_combine<T>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, a);
     hipLaunchKernelGGL((k_cluster_scale<T>), dim3(grid), dim3(256), 0, stream, a);
     MIQ_CHECK_LAUNCH("miq_cluster_scale");
     return 0;

@@ -91,15 +91,35 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
     }
 }
 
-// fold the row-chunk partials into chunk 0 (one thread per channel; a thread only touches its own column)
+// fold the row-chunk partials into chunk 0.  Block = 64 channels x 4 waves, wave w sums chunks
+// w, w+4, ...; every block only touches its own 64 columns, so folding in place is race-free once
+// all of the block's reads are done (the barrier).
 __global__ void __launch_bounds__(256) k_colbwd_fold(float* __restrict__ part, int nchunk, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sm[3][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool valid = c < C;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float v = 0.f;
-        for (int j = 0; j < nchunk; ++j) v += part[((long long)k * nchunk + j) * C + c];
-        part[((long long)k * nchunk) * C + c] = v;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (valid) {
+            const float* p = part + ((long long)k * nchunk) * C + c;
+            int j = w;
+            for (; j + 12 < nchunk; j += 16) {
+                v0 += p[(long long)j * C];
+                v1 += p[(long long)(j + 4) * C];
+                v2 += p[(long long)(j + 8) * C];
+                v3 += p[(long long)(j + 12) * C];
+            }
+            for (; j < nchunk; j += 4) v0 += p[(long long)j * C];
+        }
+        sm[k][w][lane] = (v0 + v1) + (v2 + v3);
+    }
+    __syncthreads();
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            part[((long long)k * nchunk) * C + c] = (sm[k][0][lane] + sm[k][1][lane]) + (sm[k][2][lane] + sm[k][3][lane]);
     }
 }
 
@@ -226,7 +246,7 @@ static int colquant_bwd_t(const void* g, const void* x, const void* scale, const
             hipLaunchKernelGGL((k_colbwd_stats<T, 1>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
                                (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
         const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
-        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, part, nchunk, (int)C);
+        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, part, nchunk, (int)C);
         hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(grid), dim3(256), 0, stream, part, nchunk, (int)C, chan_min, chan_max,
                            (const T*)kmin, (const T*)kmax, starts, ncl, qmax, share_min, share_max);
     }

@@ -188,7 +188,8 @@ __device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, b
         else if ((NPACK) <= 64) { LAUNCH(16, 4); }                       \
         else if ((NPACK) <= 256) { LAUNCH(64, 4); }                      \
         else if ((NPACK) <= 1024) { LAUNCH(256, 4); }                    \
-        else if ((NPACK) <= 4096) { LAUNCH(1024, 4); }                   \
+        else if ((NPACK) <= 2048) { LAUNCH(256, 8); }                    \
+        else if ((NPACK) <= 4096) { LAUNCH(512, 8); }                    \
         else { LAUNCH(1024, 8); }                                        \
     } while (0)
 
