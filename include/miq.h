@@ -129,6 +129,54 @@ int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, con
 int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int64_t C, int dtype,
                        void* stream);
 
+/*
+ * Exponential/log weight quantizer v2 (levels 0, +-1, +-2, ..., +-2^(2^(n-1)-2)), n_bits in [2, 4].
+ * Replaces ExpAffineQuantizer.per_channel_dynamic_calibration + FakeQuant.forward / backward
+ * (quantize/quantizer_exp_v2.py:186-204, :21-62, :65-105 — the backward is the reference's own
+ * hand-written rule dx = g * level/|x/s|, not the true derivative).  flags: MIQ_LWC_PREACTIVATED.
+ */
+int miq_rowquant_exp2_fwd(const void* x, const void* up, const void* low, void* out, void* scale_out,
+                          int64_t O, int64_t I, int64_t group, int n_bits, int flags, int dtype, void* stream);
+int miq_rowquant_exp2_bwd(const void* grad_out, const void* x, const void* up, const void* low, void* dx,
+                          void* d_up, void* d_low, int64_t O, int64_t I, int64_t group, int n_bits,
+                          int flags, int dtype, void* stream);
+
+/*
+ * Exponential/log weight quantizer v1 (levels +-2^e, e in [-(2^(n-1)-1), 0], no zero level).
+ * Replaces ExpAffineQuantizer.per_channel_dynamic_calibration + fake_quant and their autograd
+ * (quantize/quantizer_exp.py:143-166, :92-124).  symmetric=0 quantizes around the row midpoint,
+ * which is returned in mid_out [rows] (may be NULL when symmetric).
+ */
+int miq_rowquant_exp1_fwd(const void* x, const void* up, const void* low, void* out, void* scale_out,
+                          void* mid_out, int64_t O, int64_t I, int64_t group, int n_bits, int symmetric,
+                          int flags, int dtype, void* stream);
+int miq_rowquant_exp1_bwd(const void* grad_out, const void* x, const void* up, const void* low, void* dx,
+                          void* d_up, void* d_low, int64_t O, int64_t I, int64_t group, int n_bits,
+                          int symmetric, int flags, int dtype, void* stream);
+
+/*
+ * Learnable per-row bit-width quantizer: blend of the floor(n)- and ceil(n)-bit uniform grids.
+ * Replaces MixAffineQuantizer.forward / fake_quant and their autograd
+ * (quantize/quantizer_mix.py:143-191, :118-140).  float32 only.  n_bits [rows] must already be
+ * clamped to [2, 8] (the reference clamps the parameter in place before use, :145);
+ * hard != 0 rounds n + threshold first (:147-148).  d_nbits [rows] may be NULL.
+ */
+int miq_rowquant_mix_fwd(const void* x, const void* up, const void* low, const float* n_bits, void* out,
+                         int64_t O, int64_t I, int64_t group, int symmetric, int hard, float threshold,
+                         int flags, int dtype, void* stream);
+int miq_rowquant_mix_bwd(const void* grad_out, const void* x, const void* up, const void* low,
+                         const float* n_bits, void* dx, void* d_up, void* d_low, void* d_nbits, int64_t O,
+                         int64_t I, int64_t group, int symmetric, int hard, float threshold, int flags,
+                         int dtype, void* stream);
+
+/*
+ * RPTQ reorder index: per head, ascending stable argsort of (xmax - xmin), offset by the head start
+ * (peg_tensor_calc_reorder_index, quantize/reorder_utils.py:111-147).  xmax/xmin: f32 [C] on the
+ * device, index_out: int64 [C].  Ties are ordered by channel id; NaN ranges sort last.
+ */
+int miq_reorder_index(const float* xmax, const float* xmin, int64_t C, int n_heads, int64_t* index_out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

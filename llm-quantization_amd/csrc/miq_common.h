@@ -180,6 +180,54 @@ __device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, b
 }
 
 // ---------------------------------------------------------------------------------------------
+// Learnable weight clipping shared by all row-wise quantizers:
+//   xmax = sigmoid(up) * rowmax, xmin = sigmoid(low) * rowmin   (reference quantizer.py:259-261)
+// ---------------------------------------------------------------------------------------------
+struct ClipCtx {
+    float su, sl;      // sigmoid(up), sigmoid(low); 1 when LWC is off
+    float xmax, xmin;  // clipped bounds
+};
+
+template <typename T>
+__device__ __forceinline__ ClipCtx lwc_clip(const T* up, const T* low, int preact, long long row, float rmin, float rmax) {
+    ClipCtx c;
+    c.su = 1.f;
+    c.sl = 1.f;
+    c.xmax = rmax;
+    c.xmin = rmin;
+    if (up) {
+        c.su = to_f<T>(up[row]);
+        c.sl = to_f<T>(low[row]);
+        if (!preact) {
+            c.su = sigmoid_t<T>(c.su);
+            c.sl = sigmoid_t<T>(c.sl);
+        }
+        c.xmax = rnd<T>(c.su * rmax);
+        c.xmin = rnd<T>(c.sl * rmin);
+    }
+    return c;
+}
+
+// gradient of max(|xmax|, |xmin|): all of it to the larger magnitude, half each on a tie, times sign
+__device__ __forceinline__ void route_absmax(float d_amax, const ClipCtx& c, float& d_xmax, float& d_xmin) {
+    const float A = fabsf(c.xmax), B = fabsf(c.xmin);
+    const float da = (A > B) ? d_amax : (A == B ? 0.5f * d_amax : 0.f);
+    const float db = (B > A) ? d_amax : (A == B ? 0.5f * d_amax : 0.f);
+    d_xmax = da * sgnf(c.xmax);
+    d_xmin = db * sgnf(c.xmin);
+}
+
+// d_up / d_low from the gradients of the clipped bounds (chain through the multiply and the sigmoid)
+template <typename T>
+__device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, long long row, const ClipCtx& c,
+                                                float rmin, float rmax, float d_xmax, float d_xmin) {
+    const float ju = preact ? 1.f : c.su * (1.f - c.su);
+    const float jl = preact ? 1.f : c.sl * (1.f - c.sl);
+    d_up[row] = from_f<T>(d_xmax * rmax * ju);
+    d_low[row] = from_f<T>(d_xmin * rmin * jl);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host-side launch helper: pick (TEAM, NV) from the number of 16-byte packs in the longest row.
 // ---------------------------------------------------------------------------------------------
 #define MIQ_ROW_DISPATCH(NPACK, LAUNCH)                                  \
@@ -193,9 +241,47 @@ __device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, b
         else { LAUNCH(1024, 8); }                                        \
     } while (0)
 
+// Launch KERN<T, VEC, TEAM, NV> over all rows of GEO with the (TEAM, NV) that fits NPACK packs per row.
+#define MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, TEAM, NV, GEO, STREAM, ...)                                        \
+    {                                                                                                        \
+        constexpr int B_ = miq::block_of<TEAM>();                                                            \
+        const long long nb_ = ((GEO).n_rows + (B_ / TEAM) - 1) / (B_ / TEAM);                                \
+        hipLaunchKernelGGL((KERN<T, VECN, TEAM, NV>), dim3((unsigned)nb_), dim3(B_), 0, STREAM, __VA_ARGS__); \
+    }
+#define MIQ_ROW_LAUNCH_VEC(KERN, T, VECN, NPACK, GEO, STREAM, ...)                                   \
+    do {                                                                                             \
+        if ((NPACK) <= 16) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 16, 1, GEO, STREAM, __VA_ARGS__)        \
+        else if ((NPACK) <= 64) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 16, 4, GEO, STREAM, __VA_ARGS__)   \
+        else if ((NPACK) <= 256) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 64, 4, GEO, STREAM, __VA_ARGS__)  \
+        else if ((NPACK) <= 1024) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 4, GEO, STREAM, __VA_ARGS__) \
+        else if ((NPACK) <= 2048) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 8, GEO, STREAM, __VA_ARGS__) \
+        else if ((NPACK) <= 4096) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 8, GEO, STREAM, __VA_ARGS__) \
+        else MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 8, GEO, STREAM, __VA_ARGS__)                    \
+    } while (0)
+#define MIQ_ROW_LAUNCH(KERN, T, VEC_OK, GEO, STREAM, ...)                                            \
+    do {                                                                                             \
+        if (VEC_OK) {                                                                                \
+            MIQ_ROW_LAUNCH_VEC(KERN, T, miq::VecOf<T>::N, (GEO).g / miq::VecOf<T>::N, GEO, STREAM, __VA_ARGS__); \
+        } else {                                                                                     \
+            MIQ_ROW_LAUNCH_VEC(KERN, T, 1, (GEO).g, GEO, STREAM, __VA_ARGS__);                       \
+        }                                                                                            \
+    } while (0)
+
 constexpr int kRowMaxPacks = 8192;
 
 template <int TEAM> constexpr int block_of() { return TEAM > 256 ? TEAM : 256; }
+
+static inline bool is_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// fills GEO for an [O, I] matrix with optional grouping; returns false when the matrix is too large
+static inline bool make_geom(long long O, long long I, long long group, RowGeom& geo) {
+    if (I >= (1ll << 31)) return false;
+    geo.I = (int)I;
+    geo.g = group > 0 ? (int)group : (int)I;
+    geo.G = (int)((I + geo.g - 1) / geo.g);
+    geo.n_rows = O * geo.G;
+    return geo.n_rows < (1ll << 33);
+}
 
 }  // namespace miq
 

@@ -1,0 +1,398 @@
+// Exponential / logarithmic row-wise weight quantizers (power-of-two levels), forward + backward.
+//
+//   v2 ("exp2"): levels {0, +-1, +-2, ..., +-top}, top = 2^(2^(n-1)-2); scale = clamp(absmax/(2*top));
+//                forward and the hand-written "STE" backward follow FakeQuant.forward/backward
+//                (reference quantize/quantizer_exp_v2.py:21-105) and per_channel_dynamic_calibration
+//                (:186-204).  This is the class QuantLinear instantiates (quantize/int_linear.py:5,48).
+//   v1 ("exp1"): levels +-2^e, e in [-(2^(n-1)-1), 0], no zero level; symmetric (scale = clamp(absmax))
+//                or asymmetric around the row midpoint (reference quantize/quantizer_exp.py:92-166);
+//                the backward is what autograd derives through log2 / pow / clamp / round_ste.
+//
+// The level decision uses log2f; a value within a few ulp of a level threshold (|q| = 1.5*2^k for v2,
+// 2^(k+0.5) for v1) can land on the neighbouring level compared with another math library.
+#include "miq_common.h"
+
+namespace miq {
+
+constexpr float kLn2 = 0.693147180559945309f;  // (float)math.log(2)
+
+template <typename T>
+struct ExpArgs {
+    const T* x;
+    const T* up;
+    const T* low;
+    int n_bits;
+    int symmetric;  // v1 only
+    int preact;
+};
+
+// ------------------------------------------------------------------------------------------ v2
+struct Exp2Ctx {
+    ClipCtx clip;
+    float s, s_raw, top, qdiv;
+};
+
+template <typename T>
+__device__ __forceinline__ Exp2Ctx exp2_ctx(const ExpArgs<T>& a, long long row, float rmin, float rmax) {
+    Exp2Ctx c;
+    c.clip = lwc_clip<T>(a.up, a.low, a.preact, row, rmin, rmax);
+    c.top = (float)(1 << ((1 << (a.n_bits - 1)) - 2));
+    c.qdiv = 2.f * c.top;
+    const float amax = nmax(fabsf(c.clip.xmax), fabsf(c.clip.xmin));
+    c.s_raw = rnd<T>(amax / c.qdiv);
+    c.s = clampf(c.s_raw, rnd<T>(kClipLo), kClipHi);
+    return c;
+}
+
+struct Exp2Elem {
+    float sign, mag, lvl, signed_lvl;  // lvl: level before clamping (0 for the zero bin)
+    bool is_zero, below;
+};
+
+template <typename T>
+__device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c) {
+    Exp2Elem r;
+    const float q = rnd<T>(xv / c.s);
+    r.sign = sgnf(q);
+    const float a0 = fabsf(q);
+    r.is_zero = a0 < 0.5f;
+    r.mag = clampf(a0, rnd<T>(1e-4f), 1e4f);
+    float t = rnd<T>(rnd<T>(log2f(rnd<T>(r.mag / 1.5f))) + 0.5f);
+    r.below = t < -0.5f;
+    if (r.below) t = 0.f;
+    float e = rnd<T>(exp2f(rintf(t)));
+    if (r.is_zero) e = 0.f;
+    r.lvl = e;
+    r.signed_lvl = rnd<T>(clampf(e, -c.top, c.top) * r.sign);
+    return r;
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp2_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    long long base;
+    int len;
+    row_span(geo, row, base, len);
+    RowTile<T, VEC, TEAM, NV> x;
+    x.load(a.x + base, len, lane);
+    float rmin, rmax;
+    row_minmax(x, len < geo.g, lds, rmin, rmax);
+    const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
+    if (lane == 0) scale_out[row] = from_f<T>(c.s);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_elem<T>(to_f<T>(x.v[k].e[e]), c).signed_lvl * c.s);
+        st_pack<T, VEC>(out + base + x.offset(k), o);
+    }
+}
+
+// Reference backward (quantizer_exp_v2.py:65-105), element by element:
+//   gq   = g*s, negated where sign == -1; zeroed where the level saturates, is the zero bin, or
+//          the threshold branch was taken;  grad_q = ((ln2*lvl)*gq / ln2 / mag) * sign
+//   dx   = grad_q / s;   d_scale = g*signed_lvl + grad_q * (-x / s^2)   (summed over the row)
+// followed by autograd through clamp(scale), max(|xmax|,|xmin|), the sigmoid clipping and amax/amin.
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
+           T* __restrict__ d_low) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    long long base;
+    int len;
+    row_span(geo, row, base, len);
+    RowTile<T, VEC, TEAM, NV> x, g;
+    x.load(a.x + base, len, lane);
+    g.load(gout + base, len, lane);
+    const bool padded = len < geo.g;
+    float rmin, rmax;
+    row_minmax(x, padded, lds, rmin, rmax);
+    const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
+    auto grad_q = [&](float gv, const Exp2Elem& el) {
+        float gq = gv * c.s;
+        if (el.sign == -1.f) gq = -gq;
+        // the comparison constants are rounded to the tensor dtype, as the reference's `q_exp.ge(qmax+0.0001)` does
+        const bool dead = (el.lvl >= rnd<T>(c.top + 0.0001f)) || (el.lvl <= rnd<T>(-c.top + 0.0001f)) || el.is_zero || el.below;
+        if (dead) return 0.f;
+        return (((kLn2 * el.lvl) * gq) / kLn2 / el.mag) * el.sign;
+    };
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
+            const Exp2Elem el = exp2_elem<T>(xv, c);
+            const float gqq = grad_q(gv, el);
+            acc[0] += gv * el.signed_lvl + gqq * (-xv / (c.s * c.s));
+            acc[1] += (xv == rmax) ? 1.f : 0.f;
+            acc[2] += (xv == rmin) ? 1.f : 0.f;
+        }
+    }
+    team_sum<TEAM, 3>(acc, lds);
+    if (padded) {
+        const float npad = (float)(geo.g - len);
+        if (rmax == 0.f) acc[1] += npad;
+        if (rmin == 0.f) acc[2] += npad;
+    }
+    const bool live = c.s_raw >= rnd<T>(kClipLo) && c.s_raw <= kClipHi;
+    float d_xmax, d_xmin;
+    route_absmax(live ? acc[0] / c.qdiv : 0.f, c.clip, d_xmax, d_xmin);
+    if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+    if (dx) {
+        const float share_max = (d_xmax * c.clip.su) / acc[1];
+        const float share_min = (d_xmin * c.clip.sl) / acc[2];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            Pack<T, VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
+                float d = grad_q(gv, exp2_elem<T>(xv, c)) / c.s;
+                if (xv == rmax) d += share_max;
+                if (xv == rmin) d += share_min;
+                o.e[e] = from_f<T>(d);
+            }
+            st_pack<T, VEC>(dx + base + x.offset(k), o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ v1
+struct Exp1Ctx {
+    ClipCtx clip;
+    float s, s_raw, mid, e_lo;
+    bool has_mid;
+};
+
+template <typename T>
+__device__ __forceinline__ Exp1Ctx exp1_ctx(const ExpArgs<T>& a, long long row, float rmin, float rmax) {
+    Exp1Ctx c;
+    c.clip = lwc_clip<T>(a.up, a.low, a.preact, row, rmin, rmax);
+    c.e_lo = -(float)((1 << (a.n_bits - 1)) - 1);
+    const float lo = rnd<T>(kClipLo);
+    if (a.symmetric) {
+        c.s_raw = nmax(fabsf(c.clip.xmax), fabsf(c.clip.xmin));
+        c.has_mid = false;
+        c.mid = 0.f;
+    } else {
+        c.s_raw = rnd<T>(rnd<T>(c.clip.xmax - c.clip.xmin) / 2.f);
+        c.mid = rnd<T>(rnd<T>(c.clip.xmax + c.clip.xmin) / 2.f);
+        c.has_mid = true;
+    }
+    c.s = clampf(c.s_raw, lo, kClipHi);
+    return c;
+}
+
+struct Exp1Elem {
+    float v, u, sign, mag, lround, p;  // v = x - mid, u = v/s, mag = clamp|u|, lround = round(log2 mag), p = 2^e
+};
+
+template <typename T>
+__device__ __forceinline__ Exp1Elem exp1_elem(float xv, const Exp1Ctx& c) {
+    Exp1Elem r;
+    r.v = c.has_mid ? rnd<T>(xv - c.mid) : xv;
+    r.sign = sgnf(r.v);
+    r.u = rnd<T>(r.v / c.s);
+    r.mag = clampf(fabsf(r.u), rnd<T>(kClipLo), kClipHi);
+    const float l = rnd<T>(log2f(r.mag));
+    r.lround = rnd<T>(rnd<T>(rintf(l) - l) + l);
+    r.p = rnd<T>(exp2f(clampf(r.lround, c.e_lo, 0.f)));
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ float exp1_out(const Exp1Elem& el, const Exp1Ctx& c) {
+    float o = rnd<T>(rnd<T>(el.p * el.sign) * c.s);
+    if (c.has_mid) o = rnd<T>(o + c.mid);
+    return o;
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out, T* __restrict__ mid_out) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    long long base;
+    int len;
+    row_span(geo, row, base, len);
+    RowTile<T, VEC, TEAM, NV> x;
+    x.load(a.x + base, len, lane);
+    float rmin, rmax;
+    row_minmax(x, len < geo.g, lds, rmin, rmax);
+    const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
+    if (lane == 0) {
+        scale_out[row] = from_f<T>(c.s);
+        if (mid_out) mid_out[row] = from_f<T>(c.mid);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_out<T>(exp1_elem<T>(to_f<T>(x.v[k].e[e]), c), c));
+        st_pack<T, VEC>(out + base + x.offset(k), o);
+    }
+}
+
+// Autograd of v1.  With P = 2^e * sign, live = [e_lo <= round(log2 mag) <= 0] & [1e-5 <= |u| <= 1e4]:
+//   du = live * (ln2 * 2^e * sign * s * g) / (mag * ln2) * sgn(u)          (through pow, round_ste, log2, clamp, abs)
+//   dv = du / s;  d_s = sum g*P + sum du * (-v / s^2);  d_mid = sum g - sum dv
+//   sym : d|max| = mask * d_s;      asym: d_range = mask * d_s / 2, d_xmax = d_range + d_mid/2, d_xmin = -d_range + d_mid/2
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
+           T* __restrict__ d_low) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    long long base;
+    int len;
+    row_span(geo, row, base, len);
+    RowTile<T, VEC, TEAM, NV> x, g;
+    x.load(a.x + base, len, lane);
+    g.load(gout + base, len, lane);
+    const bool padded = len < geo.g;
+    float rmin, rmax;
+    row_minmax(x, padded, lds, rmin, rmax);
+    const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
+    const float alo = rnd<T>(kClipLo);
+    auto d_u = [&](float gv, const Exp1Elem& el) {
+        const bool live = (el.lround >= c.e_lo) && (el.lround <= 0.f) && (fabsf(el.u) >= alo) && (fabsf(el.u) <= kClipHi);
+        if (!live) return 0.f;
+        return ((kLn2 * el.p) * ((gv * c.s) * el.sign)) / (el.mag * kLn2) * sgnf(el.u);
+    };
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // d_s, d_mid, #max, #min
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
+            const Exp1Elem el = exp1_elem<T>(xv, c);
+            const float du = d_u(gv, el);
+            acc[0] += gv * (el.p * el.sign) + du * (-el.v / (c.s * c.s));
+            acc[1] += gv - du / c.s;
+            acc[2] += (xv == rmax) ? 1.f : 0.f;
+            acc[3] += (xv == rmin) ? 1.f : 0.f;
+        }
+    }
+    team_sum<TEAM, 4>(acc, lds);
+    if (padded) {
+        const float npad = (float)(geo.g - len);
+        if (rmax == 0.f) acc[2] += npad;
+        if (rmin == 0.f) acc[3] += npad;
+    }
+    const bool live_s = c.s_raw >= alo && c.s_raw <= kClipHi;
+    float d_xmax, d_xmin;
+    if (a.symmetric) {
+        route_absmax(live_s ? acc[0] : 0.f, c.clip, d_xmax, d_xmin);
+    } else {
+        const float d_range = live_s ? acc[0] / 2.f : 0.f;
+        d_xmax = d_range + acc[1] / 2.f;
+        d_xmin = -d_range + acc[1] / 2.f;
+    }
+    if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+    if (dx) {
+        const float share_max = (d_xmax * c.clip.su) / acc[2];
+        const float share_min = (d_xmin * c.clip.sl) / acc[3];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            Pack<T, VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
+                float d = d_u(gv, exp1_elem<T>(xv, c)) / c.s;
+                if (xv == rmax) d += share_max;
+                if (xv == rmin) d += share_min;
+                o.e[e] = from_f<T>(d);
+            }
+            st_pack<T, VEC>(dx + base + x.offset(k), o);
+        }
+    }
+}
+
+template <typename T>
+static int launch_exp(int which, bool backward, const void* gout, const void* x, const void* up, const void* low,
+                      void* out_or_dx, void* a1, void* a2, long long O, long long I, long long group, int n_bits,
+                      int symmetric, int flags, hipStream_t stream) {
+    const char* name = which == 2 ? (backward ? "miq_rowquant_exp2_bwd" : "miq_rowquant_exp2_fwd")
+                                  : (backward ? "miq_rowquant_exp1_bwd" : "miq_rowquant_exp1_fwd");
+    if (O == 0 || I == 0) return 0;
+    MIQ_CHECK_ARG(x && O > 0 && I > 0, "%s: null input pointer or bad shape", name);
+    MIQ_CHECK_ARG((up == nullptr) == (low == nullptr), "%s: up/low must both be given or both be null", name);
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 4, "%s: n_bits=%d outside [2,4]", name, n_bits);
+    MIQ_CHECK_ARG(backward ? (gout != nullptr) : (out_or_dx && a1), "%s: null pointer", name);
+    MIQ_CHECK_ARG(!backward || !up || (a1 && a2), "%s: d_up/d_low required when up/low are given", name);
+    RowGeom geo;
+    MIQ_CHECK_ARG(make_geom(O, I, group, geo), "%s: matrix too large", name);
+    constexpr int N = VecOf<T>::N;
+    const bool vec_ok = (I % N == 0) && (geo.g % N == 0) && is_aligned16(x) && (!out_or_dx || is_aligned16(out_or_dx)) &&
+                        (!backward || is_aligned16(gout));
+    MIQ_CHECK_ARG((vec_ok ? geo.g / N : geo.g) <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
+    ExpArgs<T> a;
+    a.x = (const T*)x;
+    a.up = (const T*)up;
+    a.low = (const T*)low;
+    a.n_bits = n_bits;
+    a.symmetric = symmetric;
+    a.preact = (flags >> 1) & 1;
+    if (which == 2) {
+        if (!backward) MIQ_ROW_LAUNCH(k_exp2_fwd, T, vec_ok, geo, stream, a, geo, (T*)out_or_dx, (T*)a1);
+        else MIQ_ROW_LAUNCH(k_exp2_bwd, T, vec_ok, geo, stream, a, geo, (const T*)gout, (T*)out_or_dx, (T*)a1, (T*)a2);
+    } else {
+        if (!backward) MIQ_ROW_LAUNCH(k_exp1_fwd, T, vec_ok, geo, stream, a, geo, (T*)out_or_dx, (T*)a1, (T*)a2);
+        else MIQ_ROW_LAUNCH(k_exp1_bwd, T, vec_ok, geo, stream, a, geo, (const T*)gout, (T*)out_or_dx, (T*)a1, (T*)a2);
+    }
+    MIQ_CHECK_LAUNCH(name);
+    return 0;
+}
+
+}  // namespace miq
+
+#define MIQ_EXP_ENTRY(WHICH, BWD, ...)                                                                      \
+    if (dtype == MIQ_F32) return miq::launch_exp<float>(WHICH, BWD, __VA_ARGS__, (hipStream_t)stream);      \
+    if (dtype == MIQ_F16) return miq::launch_exp<__half>(WHICH, BWD, __VA_ARGS__, (hipStream_t)stream);     \
+    miq_set_error("exp quantizer: unsupported dtype %d", dtype);                                            \
+    return -22;
+
+extern "C" int miq_rowquant_exp2_fwd(const void* x, const void* up, const void* low, void* out, void* scale_out,
+                                     int64_t O, int64_t I, int64_t group, int n_bits, int flags, int dtype, void* stream) {
+    MIQ_EXP_ENTRY(2, false, nullptr, x, up, low, out, scale_out, nullptr, O, I, group, n_bits, 1, flags)
+}
+
+extern "C" int miq_rowquant_exp2_bwd(const void* grad_out, const void* x, const void* up, const void* low, void* dx,
+                                     void* d_up, void* d_low, int64_t O, int64_t I, int64_t group, int n_bits, int flags,
+                                     int dtype, void* stream) {
+    MIQ_EXP_ENTRY(2, true, grad_out, x, up, low, dx, d_up, d_low, O, I, group, n_bits, 1, flags)
+}
+
+extern "C" int miq_rowquant_exp1_fwd(const void* x, const void* up, const void* low, void* out, void* scale_out,
+                                     void* mid_out, int64_t O, int64_t I, int64_t group, int n_bits, int symmetric,
+                                     int flags, int dtype, void* stream) {
+    MIQ_EXP_ENTRY(1, false, nullptr, x, up, low, out, scale_out, mid_out, O, I, group, n_bits, symmetric, flags)
+}
+
+extern "C" int miq_rowquant_exp1_bwd(const void* grad_out, const void* x, const void* up, const void* low, void* dx,
+                                     void* d_up, void* d_low, int64_t O, int64_t I, int64_t group, int n_bits,
+                                     int symmetric, int flags, int dtype, void* stream) {
+    MIQ_EXP_ENTRY(1, true, grad_out, x, up, low, dx, d_up, d_low, O, I, group, n_bits, symmetric, flags)
+}

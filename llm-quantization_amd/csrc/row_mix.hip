@@ -1,0 +1,256 @@
+// Learnable per-row bit-width ("FracBits" style) row-wise fake quantization: every row is quantized
+// on the floor(n) and ceil(n) bit grids and the two results are blended with weights (1-frac, frac).
+// Forward and backward of MixAffineQuantizer.forward / fake_quant
+// (reference quantize/quantizer_mix.py:143-191,118-140); fp32 only, like the reference's use of it.
+//
+// Backward (autograd through floor_ste / ceil_ste / round_ste, 2**b, the tensor-valued clamp bound
+// Q_b = 2^b - 1 and the scale), per grid b with g_b = g * weight_b:
+//   dS_b   = sum g_b*(xd_b - m_b*x/s_b)                    (zero when the scale clamp is active)
+//   dQ_b   = sum g_b*s_b*[level above Q_b]  +  dS_b * d(s_b)/d(Q_b)
+//   d_n   += dQ_b * ln2 * 2^b      (asym: s_b = range/Q_b;  sym: s_b = absmax/H_b, H_b = 2^(b-1)-1,
+//                                   d_n += dS_b * (-absmax/H_b^2) * ln2 * 2^(b-1) and only the clamp
+//                                   term goes through Q_b)
+//   d(blend weight)/d n cancels under the straight-through floor.
+#include "miq_common.h"
+
+namespace miq {
+
+constexpr float kLn2m = 0.693147180559945309f;
+
+struct MixArgs {
+    const float* x;
+    const float* up;
+    const float* low;
+    const float* n_bits;  // [rows] already clamped to [2, 8] by the caller
+    int symmetric;
+    int hard;
+    float threshold;
+    int preact;
+};
+
+struct Grid {
+    float b, Q, H, s, s_raw, z, w;  // bits, 2^b-1, 2^(b-1)-1, scale, unclamped scale, zero point, blend weight
+};
+
+struct MixCtx {
+    ClipCtx clip;
+    Grid lo, hi;
+    float rng, amax;
+};
+
+__device__ __forceinline__ void make_grid(Grid& gr, float b, float w, const MixCtx& c, int symmetric) {
+    gr.b = b;
+    gr.w = w;
+    gr.Q = exp2f(b) - 1.f;
+    gr.H = exp2f(b - 1.f) - 1.f;
+    if (symmetric) {
+        gr.s_raw = c.amax / gr.H;
+        gr.s = gr.s_raw;
+        gr.z = rintf(clampf(gr.H, -kClipHi, kClipHi));
+    } else {
+        gr.s_raw = c.rng / gr.Q;
+        gr.s = clampf(gr.s_raw, kClipLo, kClipHi);
+        gr.z = rintf(clampf(-c.clip.xmin / gr.s, -kClipHi, kClipHi));
+    }
+}
+
+__device__ __forceinline__ MixCtx mix_ctx(const MixArgs& a, long long row, float rmin, float rmax) {
+    MixCtx c;
+    c.clip = lwc_clip<float>(a.up, a.low, a.preact, row, rmin, rmax);
+    float n = a.n_bits[row];
+    if (a.hard) {
+        const float t = n + a.threshold;
+        n = (rintf(t) - t) + t;
+    }
+    const float nl = (floorf(n) - n) + n;
+    const float nh = (ceilf(n) - n) + n;
+    const float hp = n - nl;
+    const float lp = 1.0f - hp;
+    c.rng = c.clip.xmax - c.clip.xmin;
+    c.amax = nmax(fabsf(c.clip.xmax), fabsf(c.clip.xmin));
+    make_grid(c.lo, nl, lp, c, a.symmetric);
+    make_grid(c.hi, nh, hp, c, a.symmetric);
+    return c;
+}
+
+__device__ __forceinline__ float grid_level(float xv, const Grid& gr) {
+    const float q = xv / gr.s;
+    return ((rintf(q) - q) + q) + gr.z;
+}
+__device__ __forceinline__ float grid_fq(float xv, const Grid& gr) {
+    return (clampf(grid_level(xv, gr), 0.f, gr.Q) - gr.z) * gr.s;
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_mix_fwd(MixArgs a, RowGeom geo, float* __restrict__ out) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    long long base;
+    int len;
+    row_span(geo, row, base, len);
+    RowTile<float, VEC, TEAM, NV> x;
+    x.load(a.x + base, len, lane);
+    float rmin, rmax;
+    row_minmax(x, len < geo.g, lds, rmin, rmax);
+    const MixCtx c = mix_ctx(a, row, rmin, rmax);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+        Pack<float, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xv = x.v[k].e[e];
+            o.e[e] = c.lo.w * grid_fq(xv, c.lo) + c.hi.w * grid_fq(xv, c.hi);
+        }
+        st_pack<float, VEC>(out + base + x.offset(k), o);
+    }
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restrict__ dx, float* __restrict__ d_up,
+          float* __restrict__ d_low, float* __restrict__ d_nbits) {
+    __shared__ float lds[96];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    long long base;
+    int len;
+    row_span(geo, row, base, len);
+    RowTile<float, VEC, TEAM, NV> x, g;
+    x.load(a.x + base, len, lane);
+    g.load(gout + base, len, lane);
+    const bool padded = len < geo.g;
+    float rmin, rmax;
+    row_minmax(x, padded, lds, rmin, rmax);
+    const MixCtx c = mix_ctx(a, row, rmin, rmax);
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dS_lo, dS_hi, over_lo, over_hi, #max, #min
+    auto terms = [&](float xv, float gv, const Grid& gr, float& dS, float& over) {
+        const float gb = gv * gr.w;
+        const float q = xv / gr.s;
+        const float xi = ((rintf(q) - q) + q) + gr.z;
+        const bool m = (xi >= 0.f) && (xi <= gr.Q);
+        const float xd = clampf(xi, 0.f, gr.Q) - gr.z;
+        dS += gb * (xd - (m ? q : 0.f));
+        if (xi > gr.Q) over += gb * gr.s;
+    };
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xv = x.v[k].e[e], gv = g.v[k].e[e];
+            terms(xv, gv, c.lo, acc[0], acc[2]);
+            terms(xv, gv, c.hi, acc[1], acc[3]);
+            acc[4] += (xv == rmax) ? 1.f : 0.f;
+            acc[5] += (xv == rmin) ? 1.f : 0.f;
+        }
+    }
+    team_sum<TEAM, 6>(acc, lds);
+    if (padded) {
+        const float npad = (float)(geo.g - len);
+        if (rmax == 0.f) acc[4] += npad;
+        if (rmin == 0.f) acc[5] += npad;
+    }
+    float d_xmax, d_xmin, d_n = 0.f;
+    auto live = [](const Grid& gr) { return gr.s_raw >= kClipLo && gr.s_raw <= kClipHi; };
+    if (a.symmetric) {
+        const float dS_l = acc[0], dS_h = acc[1];
+        d_n += (dS_l * (-c.amax / (c.lo.H * c.lo.H))) * (kLn2m * exp2f(c.lo.b - 1.f));
+        d_n += (dS_h * (-c.amax / (c.hi.H * c.hi.H))) * (kLn2m * exp2f(c.hi.b - 1.f));
+        d_n += acc[2] * (kLn2m * exp2f(c.lo.b)) + acc[3] * (kLn2m * exp2f(c.hi.b));
+        route_absmax(dS_l / c.lo.H + dS_h / c.hi.H, c.clip, d_xmax, d_xmin);
+    } else {
+        const float dS_l = live(c.lo) ? acc[0] : 0.f, dS_h = live(c.hi) ? acc[1] : 0.f;
+        const float dQ_l = acc[2] + dS_l * (-c.rng / (c.lo.Q * c.lo.Q));
+        const float dQ_h = acc[3] + dS_h * (-c.rng / (c.hi.Q * c.hi.Q));
+        d_n = dQ_l * (kLn2m * exp2f(c.lo.b)) + dQ_h * (kLn2m * exp2f(c.hi.b));
+        const float d_rng = dS_l / c.lo.Q + dS_h / c.hi.Q;
+        d_xmax = d_rng;
+        d_xmin = -d_rng;
+    }
+    if (lane == 0) {
+        if (d_nbits) d_nbits[row] = d_n;
+        if (a.up) write_lwc_grads<float>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+    }
+    if (dx) {
+        const float share_max = (d_xmax * c.clip.su) / acc[4];
+        const float share_min = (d_xmin * c.clip.sl) / acc[5];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            Pack<float, VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = x.v[k].e[e], gv = g.v[k].e[e];
+                float d = 0.f;
+                {
+                    const float xi = grid_level(xv, c.lo);
+                    if (xi >= 0.f && xi <= c.lo.Q) d += ((gv * c.lo.w) * c.lo.s) / c.lo.s;
+                }
+                {
+                    const float xi = grid_level(xv, c.hi);
+                    if (xi >= 0.f && xi <= c.hi.Q) d += ((gv * c.hi.w) * c.hi.s) / c.hi.s;
+                }
+                if (xv == rmax) d += share_max;
+                if (xv == rmin) d += share_min;
+                o.e[e] = d;
+            }
+            st_pack<float, VEC>(dx + base + x.offset(k), o);
+        }
+    }
+}
+
+static int launch_mix(bool backward, const void* gout, const void* x, const void* up, const void* low, const float* n_bits,
+                      void* out_or_dx, void* d_up, void* d_low, void* d_nbits, long long O, long long I, long long group,
+                      int symmetric, int hard, float threshold, int flags, hipStream_t stream) {
+    const char* name = backward ? "miq_rowquant_mix_bwd" : "miq_rowquant_mix_fwd";
+    if (O == 0 || I == 0) return 0;
+    MIQ_CHECK_ARG(x && n_bits && O > 0 && I > 0, "%s: null input pointer or bad shape", name);
+    MIQ_CHECK_ARG((up == nullptr) == (low == nullptr), "%s: up/low must both be given or both be null", name);
+    MIQ_CHECK_ARG(backward ? (gout != nullptr) : (out_or_dx != nullptr), "%s: null pointer", name);
+    MIQ_CHECK_ARG(!backward || !up || (d_up && d_low), "%s: d_up/d_low required when up/low are given", name);
+    RowGeom geo;
+    MIQ_CHECK_ARG(make_geom(O, I, group, geo), "%s: matrix too large", name);
+    const bool vec_ok = (I % 4 == 0) && (geo.g % 4 == 0) && is_aligned16(x) && (!out_or_dx || is_aligned16(out_or_dx)) &&
+                        (!backward || is_aligned16(gout));
+    MIQ_CHECK_ARG((vec_ok ? geo.g / 4 : geo.g) <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
+    MixArgs a;
+    a.x = (const float*)x;
+    a.up = (const float*)up;
+    a.low = (const float*)low;
+    a.n_bits = n_bits;
+    a.symmetric = symmetric;
+    a.hard = hard;
+    a.threshold = threshold;
+    a.preact = (flags >> 1) & 1;
+    if (!backward) MIQ_ROW_LAUNCH(k_mix_fwd, float, vec_ok, geo, stream, a, geo, (float*)out_or_dx);
+    else MIQ_ROW_LAUNCH(k_mix_bwd, float, vec_ok, geo, stream, a, geo, (const float*)gout, (float*)out_or_dx, (float*)d_up,
+                        (float*)d_low, (float*)d_nbits);
+    MIQ_CHECK_LAUNCH(name);
+    return 0;
+}
+
+}  // namespace miq
+
+extern "C" int miq_rowquant_mix_fwd(const void* x, const void* up, const void* low, const float* n_bits, void* out,
+                                    int64_t O, int64_t I, int64_t group, int symmetric, int hard, float threshold,
+                                    int flags, int dtype, void* stream) {
+    MIQ_CHECK_ARG(dtype == MIQ_F32, "miq_rowquant_mix_fwd: float32 only");
+    return miq::launch_mix(false, nullptr, x, up, low, n_bits, out, nullptr, nullptr, nullptr, O, I, group, symmetric, hard,
+                           threshold, flags, (hipStream_t)stream);
+}
+
+extern "C" int miq_rowquant_mix_bwd(const void* grad_out, const void* x, const void* up, const void* low,
+                                    const float* n_bits, void* dx, void* d_up, void* d_low, void* d_nbits, int64_t O,
+                                    int64_t I, int64_t group, int symmetric, int hard, float threshold, int flags,
+                                    int dtype, void* stream) {
+    MIQ_CHECK_ARG(dtype == MIQ_F32, "miq_rowquant_mix_bwd: float32 only");
+    return miq::launch_mix(true, grad_out, x, up, low, n_bits, dx, d_up, d_low, d_nbits, O, I, group, symmetric, hard,
+                           threshold, flags, (hipStream_t)stream);
+}

@@ -270,3 +270,174 @@ class ActCalibFQ(torch.autograd.Function):
         dx = colquant_bwd(g.contiguous().reshape(x2.shape), x2, s, z, ctx.n_bits,
                           route=(chan_min, chan_max, kmin, kmax, ctx.layout))
         return dx.reshape(g.shape), None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# exponential / mixed-bit row-wise quantizers
+# ---------------------------------------------------------------------------------------------
+def _check_lwc(x, up, low, rows):
+    if up is not None and (up.numel() != rows or low.numel() != rows or up.dtype != x.dtype or low.dtype != x.dtype):
+        raise L.MiqError(f"LWC factors must be {rows} values of dtype {x.dtype}")
+
+
+def rowquant_exp2_fwd(x, n_bits: int, up=None, low=None, group: int = 0, preactivated: bool = False):
+    """Returns (out, scale[rows,1])."""
+    dev = L.check_gpu(x, up, low)
+    O, I, g, rows = _rows_of(x, group, up is not None)
+    _check_lwc(x, up, low, rows)
+    out = torch.empty_like(x)
+    scale = torch.empty((rows, 1), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_exp2_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(out), L.ptr(scale), L.i64(O), L.i64(I),
+               L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(x)), L.stream_of(x))
+    return out, scale
+
+
+def rowquant_exp2_bwd(grad_out, x, n_bits: int, up=None, low=None, group: int = 0, want_dx=True, preactivated=False):
+    dev = L.check_gpu(grad_out, x, up, low)
+    O, I, g, rows = _rows_of(x, group, up is not None)
+    dx = torch.empty_like(x) if want_dx else None
+    d_up = torch.empty_like(up) if up is not None else None
+    d_low = torch.empty_like(low) if low is not None else None
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_exp2_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(dx), L.ptr(d_up),
+               L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)),
+               L.i32(L.dtype_code(x)), L.stream_of(x))
+    return dx, d_up, d_low
+
+
+def rowquant_exp1_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0, preactivated=False):
+    """Returns (out, scale[rows,1], mid[rows,1]|None)."""
+    dev = L.check_gpu(x, up, low)
+    O, I, g, rows = _rows_of(x, group, up is not None)
+    _check_lwc(x, up, low, rows)
+    out = torch.empty_like(x)
+    scale = torch.empty((rows, 1), dtype=x.dtype, device=dev)
+    mid = None if symmetric else torch.empty((rows, 1), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_exp1_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(out), L.ptr(scale), L.ptr(mid), L.i64(O),
+               L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)),
+               L.i32(L.dtype_code(x)), L.stream_of(x))
+    return out, scale, mid
+
+
+def rowquant_exp1_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0, want_dx=True,
+                      preactivated=False):
+    dev = L.check_gpu(grad_out, x, up, low)
+    O, I, g, rows = _rows_of(x, group, up is not None)
+    dx = torch.empty_like(x) if want_dx else None
+    d_up = torch.empty_like(up) if up is not None else None
+    d_low = torch.empty_like(low) if low is not None else None
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_exp1_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(dx), L.ptr(d_up),
+               L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
+               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(x)), L.stream_of(x))
+    return dx, d_up, d_low
+
+
+def rowquant_mix_fwd(x, n_bits_rows, symmetric: bool, up=None, low=None, group: int = 0, hard=False, threshold=0.0,
+                     preactivated=False):
+    dev = L.check_gpu(x, up, low, n_bits_rows)
+    if x.dtype != torch.float32 or n_bits_rows.dtype != torch.float32:
+        raise L.MiqError("the learnable mixed-bit quantizer is float32 only")
+    O, I, g, rows = _rows_of(x, group, up is not None)
+    _check_lwc(x, up, low, rows)
+    if n_bits_rows.numel() != rows:
+        raise L.MiqError(f"n_bits must have {rows} entries")
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_mix_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(n_bits_rows), L.ptr(out), L.i64(O), L.i64(I),
+               L.i64(g), L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)),
+               L.i32(_flags(False, preactivated)), L.i32(L.F32), L.stream_of(x))
+    return out
+
+
+def rowquant_mix_bwd(grad_out, x, n_bits_rows, symmetric: bool, up=None, low=None, group: int = 0, hard=False,
+                     threshold=0.0, want_dx=True, preactivated=False):
+    dev = L.check_gpu(grad_out, x, up, low, n_bits_rows)
+    O, I, g, rows = _rows_of(x, group, up is not None)
+    dx = torch.empty_like(x) if want_dx else None
+    d_up = torch.empty_like(up) if up is not None else None
+    d_low = torch.empty_like(low) if low is not None else None
+    d_n = torch.empty_like(n_bits_rows)
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_mix_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(n_bits_rows), L.ptr(dx),
+               L.ptr(d_up), L.ptr(d_low), L.ptr(d_n), L.i64(O), L.i64(I), L.i64(g), L.i32(int(bool(symmetric))),
+               L.i32(int(bool(hard))), L.f32(float(threshold)), L.i32(_flags(False, preactivated)), L.i32(L.F32),
+               L.stream_of(x))
+    return dx, d_up, d_low, d_n
+
+
+class Exp2RowFQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, up, low, n_bits, group):
+        x = x.contiguous()
+        out, scale = rowquant_exp2_fwd(x, n_bits, up, low, group)
+        ctx.save_for_backward(x, up, low)
+        ctx.cfg = (n_bits, group)
+        ctx.mark_non_differentiable(scale)
+        return out, scale
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        x, up, low = ctx.saved_tensors
+        n_bits, group = ctx.cfg
+        need_dx = ctx.needs_input_grad[0]
+        if not (need_dx or (up is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))):
+            return (None,) * 5
+        dx, d_up, d_low = rowquant_exp2_bwd(g.contiguous(), x, n_bits, up, low, group, want_dx=need_dx)
+        return dx, d_up, d_low, None, None
+
+
+class Exp1RowFQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, up, low, n_bits, symmetric, group):
+        x = x.contiguous()
+        out, scale, mid = rowquant_exp1_fwd(x, n_bits, symmetric, up, low, group)
+        ctx.save_for_backward(x, up, low)
+        ctx.cfg = (n_bits, symmetric, group)
+        if mid is None:
+            mid = scale.new_empty(0)
+        ctx.mark_non_differentiable(scale, mid)
+        return out, scale, mid
+
+    @staticmethod
+    def backward(ctx, g, _gs, _gm):
+        x, up, low = ctx.saved_tensors
+        n_bits, symmetric, group = ctx.cfg
+        need_dx = ctx.needs_input_grad[0]
+        if not (need_dx or (up is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))):
+            return (None,) * 6
+        dx, d_up, d_low = rowquant_exp1_bwd(g.contiguous(), x, n_bits, symmetric, up, low, group, want_dx=need_dx)
+        return dx, d_up, d_low, None, None, None
+
+
+class MixRowFQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_bits_param, up, low, symmetric, group, hard, threshold):
+        x = x.contiguous()
+        nb = n_bits_param.detach().reshape(-1).contiguous()
+        out = rowquant_mix_fwd(x, nb, symmetric, up, low, group, hard, threshold)
+        ctx.save_for_backward(x, nb, up, low)
+        ctx.cfg = (symmetric, group, hard, threshold, n_bits_param.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, nb, up, low = ctx.saved_tensors
+        symmetric, group, hard, threshold, nshape = ctx.cfg
+        dx, d_up, d_low, d_n = rowquant_mix_bwd(g.contiguous(), x, nb, symmetric, up, low, group, hard, threshold,
+                                                want_dx=ctx.needs_input_grad[0])
+        return dx, d_n.reshape(nshape), d_up, d_low, None, None, None, None
+
+
+def reorder_index(xmax, xmin, n_heads: int = 1):
+    """int64 [C] permutation: per head, channels by ascending (xmax - xmin), ties by channel id."""
+    dev = L.check_gpu(xmax, xmin)
+    xmax = xmax.float().contiguous()
+    xmin = xmin.float().contiguous()
+    C = xmax.numel()
+    out = torch.empty(C, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        L.call("miq_reorder_index", L.ptr(xmax), L.ptr(xmin), L.i64(C), L.i32(int(n_heads)), L.ptr(out), L.stream_of(xmax))
+    return out

@@ -1,0 +1,93 @@
+"""ExpAffineQuantizer (v1: levels +-2^e without a zero level, 2..4 bits): same constructor and
+attribute surface as the reference class (quantize/quantizer_exp.py:25-174), computed by libmiq."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from ._lib import MiqError
+
+CLIPMIN = 1e-5
+
+
+class ExpAffineQuantizer(nn.Module):
+    def __init__(
+        self,
+        n_bits: int = 8,
+        symmetric: bool = True,
+        per_channel_axes=[],
+        metric="minmax",
+        dynamic=False,
+        dynamic_method="per_cluster",
+        group_size=None,
+        shape=None,
+        lwc=False,
+        target_bit=0,
+    ):
+        super().__init__()
+        self.symmetric = symmetric
+        assert 2 <= n_bits <= 4, "bitwidth not supported"
+        self.n_bits = n_bits
+        self.qmin = -(2 ** (n_bits - 1) - 1)  # one bit is spent on the sign
+        self.qmax = 0
+        self.per_channel_axes = per_channel_axes
+        self.metric = metric
+        self.cluster_counts = None
+        self.cluster_dim = None
+        self.scale = None
+        self.zero_point = None
+        self.round_zero_point = None
+        self.cached_xmin = None
+        self.cached_xmax = None
+        self.dynamic = dynamic
+        self.dynamic_method = dynamic_method
+        self.deficiency = 0
+        self.lwc = lwc
+        self.mode = "calibration"
+        init_value = 4.0
+        if lwc:
+            if group_size:
+                dim1 = int(shape[0] * math.ceil(shape[1] / group_size))
+                self.deficiency = shape[-1] % group_size
+                if self.deficiency > 0:
+                    self.deficiency = group_size - self.deficiency
+                    assert self.symmetric
+            else:
+                dim1 = shape[0]
+            self.upbound_factor = nn.Parameter(torch.ones((dim1, 1)) * init_value)
+            self.lowbound_factor = nn.Parameter(torch.ones((dim1, 1)) * init_value)
+        self.sigmoid = nn.Sigmoid()
+        self.enable = True
+        self.group_size = group_size
+
+    def change_n_bits(self, n_bits):
+        self.n_bits = n_bits
+        self.qmin = -(2 ** (n_bits - 1) - 1)
+        self.qmax = 0
+
+    def forward(self, x: torch.Tensor):
+        up = self.upbound_factor if self.lwc else None
+        low = self.lowbound_factor if self.lwc else None
+        if up is not None and up.dtype != x.dtype:
+            raise MiqError(f"LWC factors are {up.dtype} but the tensor is {x.dtype}")
+        out, scale, mid = F.Exp1RowFQ.apply(x, up, low, self.n_bits, bool(self.symmetric), int(self.group_size or 0))
+        self.scale = scale
+        self.zero_point = None if self.symmetric else mid
+        return out
+
+    def per_channel_dynamic_calibration(self, x):
+        with torch.no_grad():
+            self.forward(x)
+
+    def register_scales_and_zeros(self):
+        self.register_buffer("scales", self.scale)
+        self.register_buffer("zeros", self.zero_point)
+        del self.scale
+        del self.round_zero_point
+
+    def free(self):
+        self.cached_xmax = None
+        self.cached_xmin = None

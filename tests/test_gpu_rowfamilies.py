@@ -1,0 +1,224 @@
+"""GPU parity of the exponential (v1, v2), learnable mixed-bit and fixed mixed-bit row-wise
+quantizers and of the reorder-index kernel against the golden vectors captured from the reference.
+
+Contract:
+  * fixed / learnable mixed-bit forward: pure IEEE arithmetic -> BIT-IDENTICAL (clip factors are
+    handed over pre-activated so that the sigmoid's last bit plays no role);
+  * exponential quantizers: the level index comes from log2f.  Outputs must be bit-identical except
+    for elements whose |x/scale| lies within 8 ulp of a level threshold (0.5 and 1.5*2^k for v2,
+    2^(k+0.5) for v1), where the neighbouring level is accepted; such elements are counted and must be
+    fewer than 1e-4 of the tensor;
+  * gradients: norm-wise relative error <= 1e-5 (fp32) / 2e-2 (fp16) on entries where the
+    reference itself is finite;
+  * reorder permutations: bit-identical.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import DT, golden, rel_err, same, weight_inputs
+from miq import functional as F
+from miq import synth
+from miq.quantizer_exp import ExpAffineQuantizer as Exp1Q
+from miq.quantizer_exp_v2 import ExpAffineQuantizer as Exp2Q
+from miq.quantizer_mix import MixAffineQuantizer
+from miq.quantizer_mix_v2 import Mix2AffineQuantizer
+from oracle import miq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def masked_rel(a, ref):
+    ok = torch.isfinite(ref)
+    z = torch.zeros_like(ref)
+    return rel_err(torch.where(ok, a.detach().cpu(), z), torch.where(ok, ref, z))
+
+
+def sig(up, low):
+    return (torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)) if up is not None else (None, None)
+
+
+def chain(d_s, s):
+    """gradient w.r.t. the raw factor from the gradient w.r.t. its sigmoid"""
+    s = s.float().cpu()
+    return d_s.float().cpu() * s * (1 - s)
+
+
+def near_threshold(x, scale, kind):
+    """mask of elements whose |x/scale| is within 8 ulp (of the tensor dtype) of a level threshold"""
+    q = (x / scale).abs().double()
+    eps = 8 * (2.0 ** -23 if x.dtype == torch.float32 else 2.0 ** -10)
+    if kind == 2:
+        th = torch.tensor([0.5, 0.75] + [1.5 * 2.0 ** k for k in range(0, 16)], dtype=torch.float64)
+    else:
+        th = torch.tensor([2.0 ** (k + 0.5) for k in range(-20, 2)], dtype=torch.float64)
+    rel = ((q.unsqueeze(-1) - th) / th).abs().min(-1).values
+    return rel <= eps
+
+
+def check_exp_forward(x, scale_ref, out, ref_out, kind):
+    out = out.cpu()
+    if same(out, ref_out):
+        return 0
+    diff = ~((out == ref_out) | (torch.isnan(out) & torch.isnan(ref_out)))
+    ok = near_threshold(x, scale_ref, kind)
+    assert not bool((diff & ~ok).any()), f"{int((diff & ~ok).sum())} elements differ away from any level threshold"
+    assert diff.float().mean().item() < 1e-4
+    return int(diff.sum())
+
+
+# ------------------------------------------------------------------------------------ fixed mixed-bit
+@pytest.mark.parametrize("name", sorted(golden("mix2").keys()))
+def test_mix2_golden(name):
+    d = golden("mix2")[name]
+    m = d["meta"]
+    x, up, low, w = weight_inputs(m)
+    bits = d["bits"].to(DEV)
+    su, sl = sig(up, low)
+    out, scale, rzp, _ = F.rowquant_uniform_fwd(x.to(DEV), 0, m["symmetric"], su, sl, 0, bits, True, preactivated=True)
+    assert same(out.cpu(), d["out"])
+    # drop-in module (sigmoid fused): forward within the scale's last bits, gradients to tolerance
+    q = Mix2AffineQuantizer(target_bit=3, symmetric=m["symmetric"], per_channel_axes=[0], dynamic=True,
+                            dynamic_method="per_channel", shape=tuple(m["shape"]), mix2_nbits=d["bits"], lwc=m["lwc"]).to(DEV)
+    if m["lwc"]:
+        with torch.no_grad():
+            q.upbound_factor.copy_(up)
+            q.lowbound_factor.copy_(low)
+    xg = x.to(DEV).requires_grad_(True)
+    y = q(xg)
+    params = [q.upbound_factor, q.lowbound_factor] if m["lwc"] else []
+    g = torch.autograd.grad((y * w.to(DEV)).sum(), [xg] + params)
+    assert masked_rel(y, d["out"]) <= 1e-5
+    assert masked_rel(g[0], d["dx"]) <= 4e-5
+    if m["lwc"]:
+        assert masked_rel(g[1], d["d_up"]) <= 1e-5 and masked_rel(g[2], d["d_low"]) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------ exp v2
+@pytest.mark.parametrize("name", sorted(golden("exp2").keys()))
+def test_exp2_golden(name):
+    d = golden("exp2")[name]
+    m = d["meta"]
+    x, up, low, w = weight_inputs(m)
+    tol = 1e-5 if x.dtype == torch.float32 else 2e-2
+    su, sl = sig(up, low)
+    out, scale = F.rowquant_exp2_fwd(x.to(DEV), m["n_bits"], su, sl, preactivated=True)
+    assert same(scale.cpu(), d["scale"])
+    if m["big"]:
+        r = O.exp2_row(x, m["n_bits"], up, low)
+        assert synth.sha(r.out) == d["out_sha"]
+        ref_out = r.out
+        xg = x.clone().requires_grad_(True)
+        ps = [p.clone().requires_grad_(True) for p in (up, low)] if m["lwc"] else []
+        r = O.exp2_row(xg, m["n_bits"], *(ps if m["lwc"] else (None, None)))
+        ref_dx = torch.autograd.grad((r.out * w).sum(), [xg] + ps)[0]
+    else:
+        ref_out, ref_dx = d["out"], d["dx"]
+    nflip = check_exp_forward(x, d["scale"], out, ref_out, 2)
+    dx, d_su, d_sl = F.rowquant_exp2_bwd(w.to(DEV), x.to(DEV), m["n_bits"], su, sl, preactivated=True)
+    if nflip == 0:
+        assert masked_rel(dx, ref_dx) <= 4 * tol, masked_rel(dx, ref_dx)
+        if m["lwc"]:
+            assert masked_rel(chain(d_su, su), d["d_up"].float()) <= tol
+            assert masked_rel(chain(d_sl, sl), d["d_low"].float()) <= tol
+    # drop-in module with the fused sigmoid
+    q = Exp2Q(n_bits=m["n_bits"], symmetric=True, per_channel_axes=[0], dynamic=True, dynamic_method="per_channel",
+              shape=tuple(m["shape"]), lwc=m["lwc"])
+    q = (q.half() if x.dtype == torch.float16 else q).to(DEV)
+    if m["lwc"]:
+        with torch.no_grad():
+            q.upbound_factor.copy_(up)
+            q.lowbound_factor.copy_(low)
+    xg = x.to(DEV).requires_grad_(True)
+    y = q(xg)
+    (y.float() * w.to(DEV).float()).sum().backward()
+    assert xg.grad is not None and (not m["lwc"] or q.upbound_factor.grad is not None)
+    assert (y.detach().cpu() != ref_out).float().mean().item() < 0.02  # only rows whose scale moved by an ulp
+
+
+# ------------------------------------------------------------------------------------ exp v1
+@pytest.mark.parametrize("name", sorted(golden("exp1").keys()))
+def test_exp1_golden(name):
+    d = golden("exp1")[name]
+    m = d["meta"]
+    x, up, low, w = weight_inputs(m)
+    tol = 1e-5 if x.dtype == torch.float32 else 2e-2
+    su, sl = sig(up, low)
+    out, scale, mid = F.rowquant_exp1_fwd(x.to(DEV), m["n_bits"], m["symmetric"], su, sl, preactivated=True)
+    assert same(scale.cpu(), d["scale"])
+    if "mid" in d:
+        assert same(mid.cpu(), d["mid"])
+    xs = x if "mid" not in d else x - d["mid"]
+    nflip = check_exp_forward(xs, d["scale"], out, d["out"], 1)
+    dx, d_su, d_sl = F.rowquant_exp1_bwd(w.to(DEV), x.to(DEV), m["n_bits"], m["symmetric"], su, sl, preactivated=True)
+    if nflip == 0:
+        assert masked_rel(dx, d["dx"]) <= 4 * tol, masked_rel(dx, d["dx"])
+        if m["lwc"]:
+            assert masked_rel(chain(d_su, su), d["d_up"].float()) <= tol, masked_rel(chain(d_su, su), d["d_up"].float())
+            assert masked_rel(chain(d_sl, sl), d["d_low"].float()) <= tol
+    q = Exp1Q(n_bits=m["n_bits"], symmetric=m["symmetric"], per_channel_axes=[0], dynamic=True,
+              dynamic_method="per_channel", shape=tuple(m["shape"]), lwc=m["lwc"])
+    q = (q.half() if x.dtype == torch.float16 else q).to(DEV)
+    y = q(x.to(DEV))
+    assert y.shape == x.shape and q.scale.shape == d["scale"].shape
+
+
+# ------------------------------------------------------------------------------------ learnable mixed-bit
+@pytest.mark.parametrize("name", sorted(golden("mix").keys()))
+def test_mix_golden(name):
+    d = golden("mix")[name]
+    m = d["meta"]
+    x, up, low, w = weight_inputs(m)
+    su, sl = sig(up, low)
+    nb = d["n_bits_after"].reshape(-1).to(DEV)
+    out = F.rowquant_mix_fwd(x.to(DEV), nb, m["symmetric"], su, sl, 0, m["hard"], m["threshold"], preactivated=True)
+    assert same(out.cpu(), d["out"])
+    dx, d_su, d_sl, d_n = F.rowquant_mix_bwd(w.to(DEV), x.to(DEV), nb, m["symmetric"], su, sl, 0, m["hard"], m["threshold"],
+                                             preactivated=True)
+    assert masked_rel(dx, d["dx"]) <= 4e-5, masked_rel(dx, d["dx"])
+    assert masked_rel(d_n.reshape(-1, 1), d["d_nbits"]) <= 2e-5, masked_rel(d_n.reshape(-1, 1), d["d_nbits"])
+    if m["lwc"]:
+        assert masked_rel(chain(d_su, su), d["d_up"]) <= 1e-5
+        assert masked_rel(chain(d_sl, sl), d["d_low"]) <= 1e-5
+    # drop-in module: clamps n_bits in place, exposes the size loss
+    q = MixAffineQuantizer(target_bit=3, n_bits=d["n_bits_in"].clone(), hard_assign=m["hard"], threshold=m["threshold"],
+                           symmetric=m["symmetric"], per_channel_axes=[0], dynamic=True, dynamic_method="per_channel",
+                           shape=tuple(m["shape"]), lwc=m["lwc"]).to(DEV)
+    if m["lwc"]:
+        with torch.no_grad():
+            q.upbound_factor.copy_(up)
+            q.lowbound_factor.copy_(low)
+    xg = x.to(DEV).requires_grad_(True)
+    y = q(xg)
+    assert same(q.n_bits.detach().cpu(), d["n_bits_after"])
+    (y * w.to(DEV)).sum().backward()
+    assert masked_rel(q.n_bits.grad, d["d_nbits"]) <= 1e-3  # sigmoid fused here: scale may move by an ulp
+    ms, ts = q.model_size_loss()
+    # plain torch reductions (summation order differs between devices): equal to rounding
+    assert torch.allclose(ms.detach().cpu(), d["model_size"], rtol=1e-6) and same(ts.detach().cpu(), d["target_size"])
+    q.set_hard()
+    q.round_nbits()
+    assert not isinstance(q.n_bits, torch.nn.Parameter)
+    assert torch.equal(q.n_bits, q.n_bits.round())
+
+
+# ------------------------------------------------------------------------------------ reorder index
+@pytest.mark.parametrize("name", sorted(k for k in golden("reorder") if k.startswith("r_")))
+def test_reorder_index_golden(name):
+    d = golden("reorder")[name]
+    m = d["meta"]
+    idx = F.reorder_index(d["xmax"].to(DEV), d["xmin"].to(DEV), m["n_heads"] or 1)
+    assert torch.equal(idx.cpu(), d["index"])
+
+
+def test_reorder_index_ties_are_stable_and_large():
+    g = synth.gen(9)
+    r = torch.randint(0, 50, (11008,), generator=g).float()  # many ties
+    idx = F.reorder_index(r.to(DEV), torch.zeros_like(r).to(DEV), 1).cpu()
+    assert torch.equal(idx, torch.argsort(r, stable=True))
+    r = torch.rand(28672, generator=g)
+    idx = F.reorder_index(r.to(DEV), torch.zeros_like(r).to(DEV), 64).cpu()
+    ref, _ = O.reorder_index(r, torch.zeros_like(r), 4, 64)
+    assert torch.equal(idx, ref)
+    assert torch.equal(torch.sort(idx).values, torch.arange(28672))
