@@ -115,11 +115,15 @@ int miq_colquant_fwd(const void* x, const void* scale, const void* rzp, void* ou
  * cluster and routed to the extreme elements: chan_min/chan_max are the per-channel statistics
  * (row `nchunk` of miq_cluster_scale's partial buffers), kmin/kmax the merged [C] statistics,
  * workspace has (3*nchunk + 2)*C floats with nchunk = miq_colstat_chunks(R, C, dtype).
+ * phase 0 runs everything.  Data-parallel callers that quantize with GLOBAL-batch statistics split
+ * the call: phase 1 leaves the per-channel sums [dS, #max, #min] in workspace[0:C], [nchunk*C : +C],
+ * [2*nchunk*C : +C] (to be summed over ranks by the caller), phase 2 derives the shares from them and
+ * writes dx.
  */
 int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, const void* rzp,
                      const float* chan_min, const float* chan_max, const void* kmin, const void* kmax,
                      const int* starts, int n_clusters, int64_t covered, float* workspace, int nchunk,
-                     void* dx, int64_t R, int64_t C, int n_bits, int dtype, void* stream);
+                     void* dx, int64_t R, int64_t C, int n_bits, int phase, int dtype, void* stream);
 
 /*
  * RPTQ channel reorder: out[r, c] = x[r, idx[c]] (torch.index_select on the last axis, as in

@@ -228,7 +228,7 @@ template <typename T>
 static int colquant_bwd_t(const void* g, const void* x, const void* scale, const void* rzp, const float* chan_min,
                           const float* chan_max, const void* kmin, const void* kmax, const int* starts, int ncl,
                           long long covered, float* ws, int nchunk, void* dx, long long R, long long C, int n_bits,
-                          hipStream_t stream) {
+                          int phase, hipStream_t stream) {
     constexpr int N = VecOf<T>::N;
     const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(scale) && aligned16(rzp);
     const float qmax = (float)((1 << n_bits) - 1);
@@ -238,15 +238,21 @@ static int colquant_bwd_t(const void* g, const void* x, const void* scale, const
     float* part = ws;                                    // [3, nchunk, C]
     float* share_min = ws + 3ll * nchunk * C;            // [C]
     float* share_max = share_min + C;                    // [C]
-    if (route) {
+    if (route && phase != 2) {
         if (vec_ok)
             hipLaunchKernelGGL((k_colbwd_stats<T, N>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
                                (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
         else
             hipLaunchKernelGGL((k_colbwd_stats<T, 1>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
                                (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
-        const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
         hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, part, nchunk, (int)C);
+    }
+    if (phase == 1) {
+        MIQ_CHECK_LAUNCH("miq_colquant_bwd");
+        return 0;
+    }
+    if (route) {
+        const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
         hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(grid), dim3(256), 0, stream, part, nchunk, (int)C, chan_min, chan_max,
                            (const T*)kmin, (const T*)kmax, starts, ncl, qmax, share_min, share_max);
     }
@@ -271,20 +277,21 @@ using namespace miq;
 extern "C" int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, const void* rzp,
                                 const float* chan_min, const float* chan_max, const void* kmin, const void* kmax,
                                 const int* starts, int n_clusters, int64_t covered, float* workspace, int nchunk,
-                                void* dx, int64_t R, int64_t C, int n_bits, int dtype, void* stream) {
+                                void* dx, int64_t R, int64_t C, int n_bits, int phase, int dtype, void* stream) {
     if (R == 0 || C == 0) return 0;
-    MIQ_CHECK_ARG(grad_out && x && scale && rzp && dx && R > 0 && C > 0 && C < (1ll << 31),
+    MIQ_CHECK_ARG(grad_out && x && scale && rzp && (dx || phase == 1) && R > 0 && C > 0 && C < (1ll << 31),
                   "miq_colquant_bwd: null pointer or bad shape");
+    MIQ_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 0 || chan_min), "miq_colquant_bwd: phase %d needs the routing inputs", phase);
     MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && nchunk >= 1, "miq_colquant_bwd: bad n_bits/nchunk");
     MIQ_CHECK_ARG((chan_min == nullptr) == (chan_max == nullptr), "miq_colquant_bwd: chan_min/chan_max must come together");
     MIQ_CHECK_ARG(!chan_min || (kmin && kmax && starts && workspace && covered >= 0 && covered <= C),
                   "miq_colquant_bwd: routing needs kmin, kmax, starts and a workspace");
     if (dtype == MIQ_F32)
         return colquant_bwd_t<float>(grad_out, x, scale, rzp, chan_min, chan_max, kmin, kmax, starts, n_clusters, covered,
-                                     workspace, nchunk, dx, R, C, n_bits, (hipStream_t)stream);
+                                     workspace, nchunk, dx, R, C, n_bits, phase, (hipStream_t)stream);
     if (dtype == MIQ_F16)
         return colquant_bwd_t<__half>(grad_out, x, scale, rzp, chan_min, chan_max, kmin, kmax, starts, n_clusters, covered,
-                                      workspace, nchunk, dx, R, C, n_bits, (hipStream_t)stream);
+                                      workspace, nchunk, dx, R, C, n_bits, phase, (hipStream_t)stream);
     miq_set_error("miq_colquant_bwd: unsupported dtype %d", dtype);
     return -22;
 }

@@ -1,0 +1,268 @@
+"""Quantized decoder blocks assembled from the drop-in wrappers.  They are the objects the
+block-calibration loop drives; attribute and parameter names follow the reference's
+QuantOPTDecoderLayer (models/int_opt_layer.py:251-511) so that ``omni_state_dict`` produces the same
+keys as the reference's ``omni_parameters.pth`` (``self_attn.q_proj.weight_quantizer.upbound_factor``,
+``qkv_smooth_scale`` ...).
+
+The attention / MLP arithmetic itself (GEMMs, softmax, activation) is plain PyTorch-ROCm: it is not
+part of the fake-quantization path, only its caller.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from .int_linear import QuantLinear
+from .int_matmul import QuantMatMul
+from .let import (smooth_fc_fc_inplace, smooth_fc_fc_temporary, smooth_ln_fcs_inplace, smooth_ln_fcs_temporary,
+                  smooth_q_k_inplace, smooth_q_k_temporary, truncate_number)
+from .omni_norm import OmniLayerNorm, OmniLlamaRMSNorm
+
+
+def quant_args(wbits=4, abits=4, w_symmetric=False, group_size=None, lwc=True, a_dynamic_method="per_cluster",
+               a_dynamic=False, metric="ema_minmax", weight_exp_quant=False, weight_mix_quant=False,
+               weight_mix2_quant=False, let=True):
+    """Quantizer keyword dictionaries as the reference's CLI builds them (main.py:332-380)."""
+    a = SimpleNamespace()
+    a.weight_quant_params = {
+        "n_bits": wbits if not weight_mix_quant else [], "per_channel_axes": [0], "symmetric": w_symmetric,
+        "dynamic_method": "per_channel", "group_size": group_size, "lwc": lwc, "dynamic": True, "metric": "minmax",
+        "target_bit": wbits,
+    }
+    act = {"n_bits": abits, "per_channel_axes": [], "symmetric": False, "dynamic_method": a_dynamic_method,
+           "dynamic": a_dynamic, "metric": metric}
+    a.act_quant_params = dict(act)
+    a.q_quant_params = dict(act)
+    a.k_quant_params = dict(act)
+    a.v_quant_params = dict(act)
+    a.p_quant_params = {"n_bits": 16, "metric": "fix0to1"}  # attention probabilities stay unquantized
+    a.weight_exp_quant = weight_exp_quant
+    a.weight_mix_quant = weight_mix_quant
+    a.weight_mix2_quant = weight_mix2_quant
+    a.let = let
+    return a
+
+
+def _linear(w, b):
+    l = nn.Linear(w.shape[1], w.shape[0], bias=b is not None, device=w.device, dtype=w.dtype)
+    with torch.no_grad():
+        l.weight.copy_(w)
+        if b is not None:
+            l.bias.copy_(b)
+    return l
+
+
+class _BlockBase(nn.Module):
+    """Calibration plumbing shared by the block flavours."""
+
+    let = False
+
+    def quant_linears(self):
+        return [(n, m) for n, m in self.named_modules() if isinstance(m, QuantLinear)]
+
+    def act_quantizers(self):
+        for _n, m in self.named_modules():
+            if isinstance(m, QuantLinear) and not m.disable_input_quant:
+                yield m.act_quantizer
+            if isinstance(m, QuantMatMul):
+                yield m.x1_quantizer
+                yield m.x2_quantizer
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+        for _n, m in self.named_modules():
+            if isinstance(m, (QuantLinear, QuantMatMul)):
+                m.set_quant_state(weight_quant, act_quant)
+
+    def clear_temp_variable(self):
+        for _n, m in self.quant_linears():
+            del m.temp_weight
+            del m.temp_bias
+
+    def _named(self, *needles):
+        return iter([p for n, p in self.named_parameters() if any(n.find(s) > -1 for s in needles)])
+
+    def let_parameters(self, use_shift=True):
+        return self._named("smooth" if use_shift else "smooth_scale")
+
+    def lwc_parameters(self):
+        return self._named("bound_factor")
+
+    def nbits_parameters(self):
+        return self._named("n_bits")
+
+    def omni_parameters(self, use_shift=True):
+        return self._named("bound_factor", "smooth" if use_shift else "smooth_scale")
+
+    def omni_state_dict(self, destination=None, prefix="", keep_vars=False):
+        if destination is None:
+            destination = OrderedDict()
+        for name, param in self.named_parameters():
+            if name.find("smooth") > -1 or name.find("bound_factor") > -1:
+                destination[prefix + name] = param if keep_vars else param.detach()
+        return destination
+
+    def register_scales_and_zeros(self):
+        for _n, m in self.quant_linears():
+            m.weight_quantizer.register_scales_and_zeros()
+
+    def get_size_loss(self):
+        mods = [m for _n, m in self.quant_linears()]
+        dev = mods[0].weight.device
+        model_sizes = torch.zeros((len(mods), 1), device=dev)
+        target_sizes = torch.zeros((len(mods), 1), device=dev)
+        for i, m in enumerate(mods):
+            model_sizes[i], target_sizes[i] = m.weight_quantizer.model_size_loss()
+        return model_sizes, target_sizes
+
+    def set_hard_quant(self):
+        for _n, m in self.quant_linears():
+            m.weight_quantizer.set_hard()
+
+    def round_nbits(self):
+        for _n, m in self.quant_linears():
+            m.weight_quantizer.round_nbits()
+
+    def _quantize_temp_weights(self):
+        for _n, m in self.quant_linears():
+            src = m.temp_weight if hasattr(m, "temp_weight") else m.weight
+            m.temp_weight = m.weight_quantizer(src)
+            if not hasattr(m, "temp_bias"):
+                m.temp_bias = m.bias
+            m.use_temporary_parameter = True
+
+    def _truncate_scales(self):
+        with torch.no_grad():
+            for n, p in self.named_parameters():
+                if "smooth_scale" in n:
+                    p.data = truncate_number(p)
+
+
+class _OPTAttention(nn.Module):
+    def __init__(self, q, k, v, o, num_heads, args, nbits=None):
+        super().__init__()
+        self.embed_dim = q.weight.shape[1]
+        self.num_heads = num_heads
+        self.head_dim = self.embed_dim // num_heads
+        assert self.head_dim * num_heads == self.embed_dim
+        self.scaling = self.head_dim ** -0.5
+        kw = dict(weight_exp_quant=args.weight_exp_quant, weight_mix_quant=args.weight_mix_quant,
+                  weight_mix2_quant=args.weight_mix2_quant)
+        nb = nbits or {}
+        self.k_proj = QuantLinear(k, args.weight_quant_params, args.act_quant_params, False, weight_nbits=nb.get("k", []), **kw)
+        self.v_proj = QuantLinear(v, args.weight_quant_params, args.act_quant_params, False, weight_nbits=nb.get("v", []), **kw)
+        self.q_proj = QuantLinear(q, args.weight_quant_params, args.act_quant_params, False, weight_nbits=nb.get("q", []), **kw)
+        self.out_proj = QuantLinear(o, args.weight_quant_params, args.act_quant_params, False, weight_nbits=nb.get("o", []), **kw)
+        self.qkt_matmul = QuantMatMul(args.q_quant_params, args.k_quant_params, matmul_func=torch.bmm)
+        self.pv_matmul = QuantMatMul(args.p_quant_params, args.v_quant_params, matmul_func=torch.bmm)
+
+    def _heads(self, t, bsz):
+        return t.view(bsz, -1, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
+
+    def forward(self, hidden_states, attention_mask=None):
+        bsz, tgt_len, _ = hidden_states.size()
+        q = self.qkt_matmul.quant_x1(self.q_proj(hidden_states) * self.scaling)
+        k = self._heads(self.qkt_matmul.quant_x2(self.k_proj(hidden_states)), bsz)
+        v = self._heads(self.pv_matmul.quant_x2(self.v_proj(hidden_states)), bsz)
+        shape = (bsz * self.num_heads, -1, self.head_dim)
+        q = self._heads(q, bsz).view(*shape)
+        k = k.view(*shape)
+        v = v.view(*shape)
+        src_len = k.size(1)
+        w = self.qkt_matmul(q, k.transpose(1, 2))
+        if attention_mask is not None:
+            w = w.view(bsz, self.num_heads, tgt_len, src_len) + attention_mask
+            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+            w = w.view(bsz * self.num_heads, tgt_len, src_len)
+        if w.dtype == torch.float16:
+            w = TF.softmax(w, dim=-1, dtype=torch.float32).to(torch.float16)
+        else:
+            w = TF.softmax(w, dim=-1)
+        w = self.pv_matmul.quant_x1(w)
+        o = self.pv_matmul(w, v)
+        o = o.view(bsz, self.num_heads, tgt_len, self.head_dim).transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
+        return self.out_proj(o)
+
+
+class QuantOPTBlock(_BlockBase):
+    """Pre-LN OPT decoder block (layer norm -> attention -> residual; layer norm -> fc1 -> ReLU ->
+    fc2 -> residual), the layout of the reference's QuantOPTDecoderLayer.
+
+    ``weights``: dict with 2-D tensors q,k,v,o,fc1,fc2, biases q_b..fc2_b, and ln1_w, ln1_b, ln2_w,
+    ln2_b.  ``nbits``: optional dict of per-row bit tensors for the fixed mixed-bit quantizer.
+    """
+
+    def __init__(self, weights: dict, num_heads: int, args, nbits=None, eps=1e-5):
+        super().__init__()
+        w = weights
+        H = w["q"].shape[1]
+        self.embed_dim = H
+        self.self_attn = _OPTAttention(_linear(w["q"], w.get("q_b")), _linear(w["k"], w.get("k_b")),
+                                       _linear(w["v"], w.get("v_b")), _linear(w["o"], w.get("o_b")), num_heads, args, nbits)
+        self.do_layer_norm_before = True
+        ln1 = nn.LayerNorm(H, eps=eps, device=w["q"].device, dtype=w["q"].dtype)
+        ln2 = nn.LayerNorm(H, eps=eps, device=w["q"].device, dtype=w["q"].dtype)
+        with torch.no_grad():
+            ln1.weight.copy_(w["ln1_w"]); ln1.bias.copy_(w["ln1_b"])
+            ln2.weight.copy_(w["ln2_w"]); ln2.bias.copy_(w["ln2_b"])
+        self.self_attn_layer_norm = OmniLayerNorm(ln1)
+        kw = dict(weight_exp_quant=args.weight_exp_quant, weight_mix_quant=args.weight_mix_quant,
+                  weight_mix2_quant=args.weight_mix2_quant)
+        nb = nbits or {}
+        self.fc1 = QuantLinear(_linear(w["fc1"], w.get("fc1_b")), args.weight_quant_params, args.act_quant_params,
+                               weight_nbits=nb.get("fc1", []), **kw)
+        self.fc2 = QuantLinear(_linear(w["fc2"], w.get("fc2_b")), args.weight_quant_params, args.act_quant_params,
+                               weight_nbits=nb.get("fc2", []), **kw)
+        self.final_layer_norm = OmniLayerNorm(ln2)
+        self.type = w["fc1"].dtype
+        self.let = bool(getattr(args, "let", False))
+        self.num_heads = num_heads
+
+    def forward(self, hidden_states, attention_mask=None, **_kw):
+        residual = hidden_states
+        h = self.self_attn_layer_norm(hidden_states)
+        h = self.self_attn(h, attention_mask=attention_mask)
+        h = residual + h
+        shape = h.shape
+        h = h.reshape(-1, h.size(-1))
+        residual = h
+        h = self.final_layer_norm(h)
+        h = self.fc2(TF.relu(self.fc1(h)))
+        return ((residual + h).view(shape),)
+
+    def smooth_and_quant_temporary(self):
+        a = self.self_attn
+        if self.let:
+            self._truncate_scales()
+            smooth_ln_fcs_temporary(self.self_attn_layer_norm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
+                                    self.qkv_smooth_shift)
+            smooth_ln_fcs_temporary(self.final_layer_norm, [self.fc1], self.fc1_smooth_scale, self.fc1_smooth_shift)
+            smooth_fc_fc_temporary(a.v_proj, a.out_proj, self.out_smooth_scale, self.out_smooth_shift)
+            smooth_q_k_temporary(a.q_proj, a.k_proj, self.qkt_smooth_scale)
+            self.fc2.temp_weight = self.fc2.weight
+        else:
+            for _n, m in self.quant_linears():
+                m.temp_weight = m.weight
+        self._quantize_temp_weights()
+
+    @torch.no_grad()
+    def smooth_and_quant_inplace(self):
+        a = self.self_attn
+        if self.let:
+            self._truncate_scales()
+            smooth_ln_fcs_inplace(self.self_attn_layer_norm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
+                                  self.qkv_smooth_shift)
+            smooth_ln_fcs_inplace(self.final_layer_norm, [self.fc1], self.fc1_smooth_scale, self.fc1_smooth_shift)
+            smooth_fc_fc_inplace(a.v_proj, a.out_proj, self.out_smooth_scale, self.out_smooth_shift)
+            smooth_q_k_inplace(a.q_proj, a.k_proj, self.qkt_smooth_scale)
+        for _n, m in self.quant_linears():
+            m.weight = m.weight_quantizer(m.weight)
+            m.use_temporary_parameter = False
+
+    # names of the linears that receive a LET scale/shift pair, and the reorder index each pair follows
+    LET_PAIRS = {"q_proj": ("qkv", "R1"), "out_proj": ("out", "R3"), "fc1": ("fc1", "R4")}

@@ -1,0 +1,386 @@
+"""Block-wise OmniQuant calibration of one quantized decoder block, with optional data parallelism.
+
+Restates the per-layer part of the reference's ``omniquant()`` (quantize/omniquant.py:366-605):
+reorder statistics -> ``Reorder`` -> full-precision targets -> LET initialisation -> AdamW loop over
+(epochs x samples) with temporary smoothing + weight fake-quant, MSE against the targets, loss
+scaling, per-step ``free()`` of the activation statistics -> in-place smoothing/quantization ->
+sequential propagation of the quantized activations (this is where the static activation scales
+accumulate) -> ``register_scales_and_zeros`` -> eval mode.
+
+Data parallelism (one process per GPU): the calibration samples are sharded over the ranks; every
+optimizer step each rank runs one local batch and the LWC/LET gradients are averaged with one packed
+all-reduce, so the parameter trajectories stay identical on all ranks.  The final propagation pass is
+order dependent (running min/max or EMA over the samples, each sample quantized with the statistics
+of its prefix) and is therefore replicated: the owner broadcasts each sample, every rank runs it, the
+owner keeps the result.
+"""
+from __future__ import annotations
+
+import math
+import os
+from contextlib import nullcontext
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import reorder_utils as R
+from .dist import DPContext, allreduce_mean_grads, broadcast_from, owner_of, shard_range
+from .int_linear import QuantLinear
+from .int_matmul import QuantMatMul
+from .omni_norm import OmniLayerNorm
+
+
+@dataclass
+class CalibConfig:
+    epochs: int = 20
+    nsamples: int = 128
+    batch_size: int = 1
+    let: bool = True
+    lwc: bool = True
+    let_lr: float = 5e-3
+    lwc_lr: float = 1e-2
+    wd: float = 0.0
+    alpha: float = 0.5
+    deactive_amp: bool = True
+    reorder: str = ""                      # e.g. "012345": "0" enables clustering, "1".."5" the R stages
+    n_clusters: Dict[str, int] = field(default_factory=lambda: {"R1": 32, "R2": 4, "R3": 4, "R4": 32, "R5": 32})
+    weight_mix_quant: bool = False
+    loss_size_coef: float = 0.0
+    use_shift: bool = True
+
+
+class LossScaler:
+    """GradScaler wrapper returning the gradient norm, optionally averaging gradients over ranks
+    between backward and unscale (reference: utils.NativeScalerWithGradNormCount, utils.py:26-52)."""
+
+    def __init__(self, device_type: str = "cuda"):
+        self._scaler = torch.amp.GradScaler(device_type, enabled=(device_type == "cuda" and torch.cuda.is_available()))
+
+    def __call__(self, loss, optimizer, parameters, dp: Optional[DPContext] = None, buf=None):
+        self._scaler.scale(loss).backward()
+        parameters = list(parameters)
+        if dp is not None and dp.active:
+            buf = allreduce_mean_grads(parameters, dp, buf)
+        self._scaler.unscale_(optimizer)
+        norm = grad_norm(parameters)
+        self._scaler.step(optimizer)
+        self._scaler.update()
+        return norm, buf
+
+
+def grad_norm(parameters, norm_type: float = 2.0):
+    ps = [p for p in parameters if p.grad is not None]
+    if not ps:
+        return torch.tensor(0.0)
+    dev = ps[0].grad.device
+    return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(dev) for p in ps]), norm_type)
+
+
+# ------------------------------------------------------------------------------------------------
+# reorder: statistics hooks and the R1..R5 wiring of a block
+# ------------------------------------------------------------------------------------------------
+def register_hooks(layer, enable_R1, enable_R2, enable_R3, enable_R4, enable_R5):
+    """Statistics hooks by module name (reference omniquant.py:167-210).  Works on a plain fp block
+    (nn.LayerNorm / nn.Linear) and on a quantized block run with quantization off."""
+    norms = (nn.LayerNorm, OmniLayerNorm)
+    linears = (nn.Linear, QuantLinear)
+    handlers = []
+    for name, module in layer.named_modules():
+        hook = None
+        if enable_R1 and isinstance(module, norms) and "attn_layer_norm" in name:
+            hook = R.layer_omax_hook
+        if enable_R2 and isinstance(module, linears) and ("q_proj" in name or "k_proj" in name):
+            hook = R.layer_omax_hook
+        if enable_R3 and isinstance(module, linears) and "out_proj" in name:
+            hook = R.layer_i0max_hook
+        if enable_R4 and isinstance(module, norms) and "final_layer_norm" in name:
+            hook = R.layer_omax_hook
+        if enable_R5 and isinstance(module, linears) and "fc2" in name:
+            hook = R.layer_i0max_hook
+        if hook is not None:
+            module.name = name
+            handlers.append(module.register_forward_hook(hook))
+    return handlers
+
+
+def sync_reorder_stats(dp: Optional[DPContext]):
+    """Running max/min gathered from a sample shard -> global (one MAX all-reduce per dictionary)."""
+    if dp is None or not dp.active:
+        return
+    import torch.distributed as dist
+
+    for store in (R.oc_maxmin_dict, R.ic_maxmin_dict):
+        names = sorted(store)
+        if not names:
+            continue
+        packed = torch.cat([torch.cat((store[n][0].float(), -store[n][1].float())) for n in names])
+        dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=dp.group)
+        off = 0
+        for n in names:
+            c = store[n][0].numel()
+            store[n] = (packed[off:off + c].to(store[n][0].dtype), (-packed[off + c:off + 2 * c]).to(store[n][1].dtype))
+            off += 2 * c
+
+
+def reorder_block(qlayer, hidden_size, ffn_dim, num_heads, enable, n_clusters, dev):
+    """R1..R5 (reference omniquant.py:31-165).  A disabled stage still wires an identity index and
+    equal-size clusters, and the identity gather still runs in the layer norms."""
+    a = qlayer.self_attn
+    indices = {}
+
+    def even(total, k):
+        return (np.ones(int(k), dtype=int) * (total / k)).astype(int)
+
+    if not enable["R1"]:
+        idx, counts = torch.arange(hidden_size).to(dev), even(hidden_size, n_clusters["R1"])
+    else:
+        fmax, fmin = R.oc_maxmin_dict["self_attn_layer_norm"]
+        idx, counts = R.tensor_calc_reorder_index(fmax, fmin, n_clusters["R1"])
+    R.R1_reorder(qlayer.self_attn_layer_norm, a.q_proj, a.k_proj, a.v_proj, idx, counts)
+    indices["R1"] = idx
+
+    if not enable["R2"]:
+        idx, counts = torch.arange(hidden_size).to(dev), even(hidden_size, n_clusters["R2"] * num_heads)
+    else:
+        qmax, qmin = R.oc_maxmin_dict["self_attn.q_proj"]
+        kmax, kmin = R.oc_maxmin_dict["self_attn.k_proj"]
+        idx, counts = R.tensor_calc_reorder_index([qmax, kmax], [qmin, kmin], n_clusters["R2"], num_heads)
+    R.R2_reorder(a.q_proj, a.k_proj, a.qkt_matmul, idx, counts)
+    indices["R2"] = idx
+
+    if not enable["R3"]:
+        idx, counts = torch.arange(hidden_size).to(dev), even(hidden_size, n_clusters["R3"] * num_heads)
+    else:
+        fmax, fmin = R.ic_maxmin_dict["self_attn.out_proj"]
+        idx, counts = R.tensor_calc_reorder_index(fmax, fmin, n_clusters["R3"], num_heads)
+    R.R3_reorder(a.v_proj, a.pv_matmul, a.out_proj, idx, counts)
+    indices["R3"] = idx
+
+    if not enable["R4"]:
+        idx, counts = torch.arange(hidden_size).to(dev), even(hidden_size, n_clusters["R4"])
+    else:
+        fmax, fmin = R.oc_maxmin_dict["final_layer_norm"]
+        idx, counts = R.tensor_calc_reorder_index(fmax, fmin, n_clusters["R4"])
+    R.R4_reorder(qlayer.final_layer_norm, qlayer.fc1, idx, counts)
+    indices["R4"] = idx
+
+    if not enable["R5"]:
+        idx, counts = torch.arange(ffn_dim).to(dev), even(ffn_dim, n_clusters["R5"])
+    else:
+        fmax, fmin = R.ic_maxmin_dict["fc2"]
+        idx, counts = R.tensor_calc_reorder_index(fmax, fmin, n_clusters["R5"])
+    R.R5_reorder(qlayer.fc1, qlayer.fc2, idx, counts)
+    indices["R5"] = idx
+    return indices
+
+
+# ------------------------------------------------------------------------------------------------
+# LET initialisation
+# ------------------------------------------------------------------------------------------------
+def init_let(qlayer, act_scales: Dict[str, torch.Tensor], act_shifts: Dict[str, torch.Tensor], layer_prefix: str,
+             cfg: CalibConfig, indices: Optional[dict], dtype, dev, is_llama=False):
+    """SmoothQuant-style initial scales act^alpha / w^(1-alpha) and shifts (reference omniquant.py:417-446)."""
+    pairs = getattr(qlayer, "LET_PAIRS", {})
+    first = next(m for _n, m in qlayer.named_modules() if isinstance(m, QuantLinear) and "q_proj" in _n)
+    qlayer.register_parameter("qkt_smooth_scale", nn.Parameter(torch.ones(first.out_features, device=dev, dtype=dtype)))
+    for name, module in qlayer.named_modules():
+        if not isinstance(module, QuantLinear):
+            continue
+        for key, (tag, rstage) in pairs.items():
+            if key not in name:
+                continue
+            act = act_scales[f"{layer_prefix}.{name}"].to(device=dev, dtype=dtype).clamp(min=1e-5)
+            if indices is not None:
+                act = torch.index_select(act, 0, indices[rstage].to(dev))
+            weight = module.weight.max(dim=0)[0].clamp(min=1e-5)
+            scale = (act.pow(cfg.alpha) / weight.pow(1 - cfg.alpha)).clamp(min=1e-5)
+            if cfg.use_shift and not is_llama:
+                shift = act_shifts[f"{layer_prefix}.{name}"].to(device=dev, dtype=dtype)
+                if indices is not None:
+                    shift = torch.index_select(shift, 0, indices[rstage].to(dev))
+            else:
+                shift = torch.zeros_like(scale)
+            qlayer.register_parameter(f"{tag}_smooth_shift", nn.Parameter(shift))
+            qlayer.register_parameter(f"{tag}_smooth_scale", nn.Parameter(scale))
+
+
+# ------------------------------------------------------------------------------------------------
+# the per-layer calibration
+# ------------------------------------------------------------------------------------------------
+def _free_act_stats(qlayer):
+    for _n, m in qlayer.named_modules():
+        if isinstance(m, QuantLinear) and not m.disable_input_quant:
+            m.act_quantizer.free()
+        if isinstance(m, QuantMatMul):
+            m.x1_quantizer.free()
+            m.x2_quantizer.free()
+
+
+def _set_eval(qlayer):
+    for _n, m in qlayer.named_modules():
+        if isinstance(m, QuantLinear) and not m.disable_input_quant:
+            m.act_quantizer.set_eval_mode()
+        if isinstance(m, QuantMatMul):
+            m.x1_quantizer.set_eval_mode()
+            m.x2_quantizer.set_eval_mode()
+
+
+def _set_dp(qlayer, dp):
+    for q in qlayer.act_quantizers():
+        q.dp = dp if (dp is not None and dp.active and dp.sync_stats) else None
+
+
+def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfig, act_scales=None, act_shifts=None,
+                    layer_prefix: str = "model.decoder.layers.0", dims=None, dp: Optional[DPContext] = None,
+                    position_ids=None, logger=None, reorder_stats_layer=None, indices=None, is_llama=False):
+    """Calibrate ONE block in place.
+
+    quant_inps / fp_inps: [n_local, T, H] tensors holding THIS rank's shard of the calibration
+    samples (all samples when dp is None); both are overwritten with the block's outputs, as the
+    reference does.  ``dims`` = (hidden, ffn, heads) is needed when reordering.
+    Returns a dict with the per-step losses / gradient norms and the reorder indices.
+    """
+    dp = dp or DPContext()
+    dev = quant_inps.device
+    n_local = quant_inps.shape[0]
+    n_total = cfg.nsamples
+    use_amp = not cfg.deactive_amp
+    dtype = torch.float32 if (cfg.deactive_amp and cfg.epochs > 0) else torch.float16
+    traincast = (lambda: torch.autocast("cuda", dtype=torch.float16)) if use_amp else nullcontext
+    loss_func = nn.MSELoss()
+    mask_batch = None
+    if attention_mask is not None:
+        mask_batch = attention_mask.repeat(cfg.batch_size, 1, 1, 1)
+        mask_batch = mask_batch if cfg.deactive_amp else mask_batch.float()
+
+    # ---- reorder ---------------------------------------------------------------------------
+    if "0" in cfg.reorder and indices is None:
+        enable = {f"R{k}": (str(k) in cfg.reorder) for k in range(1, 6)}
+        # the reference gathers the statistics from the ORIGINAL block in fp16 (omniquant.py:376-382);
+        # without one, the quantized block is run with quantization switched off
+        src = reorder_stats_layer if reorder_stats_layer is not None else qlayer
+        handlers = register_hooks(src, *[enable[f"R{k}"] for k in range(1, 6)])
+        if src is qlayer:
+            qlayer.set_quant_state(False, False)
+        with torch.no_grad():
+            for j in range(n_local):
+                xj = quant_inps[j].unsqueeze(0)
+                if reorder_stats_layer is not None:
+                    xj = xj.to(torch.float16)
+                src(xj, attention_mask=attention_mask)
+        for h in handlers:
+            h.remove()
+        sync_reorder_stats(dp)
+        hidden, ffn, heads = dims
+        indices = reorder_block(qlayer, hidden, ffn, heads, enable, cfg.n_clusters, dev)
+
+    # ---- full-precision targets -------------------------------------------------------------
+    qlayer.set_quant_state(weight_quant=False, act_quant=False)
+    if cfg.epochs > 0:
+        if not use_amp:
+            with torch.no_grad():
+                qlayer.float()  # fp32 path: without autocast the block must match the fp32 activations
+        with torch.no_grad(), (torch.autocast("cuda", dtype=torch.float16) if use_amp else nullcontext()):
+            for j in range(n_local):
+                fp_inps[j] = qlayer(fp_inps[j].unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]
+
+    qlayer.set_quant_state(weight_quant=False, act_quant=True)  # weights are quantized by hand before each forward
+    qlayer.let = cfg.let
+    if cfg.let:
+        init_let(qlayer, act_scales, act_shifts, layer_prefix, cfg, indices, dtype, dev, is_llama)
+    _set_dp(qlayer, dp)
+
+    losses: List[float] = []
+    norms: List[float] = []
+    if cfg.epochs > 0:
+        with torch.no_grad():
+            qlayer.float()
+        groups = []
+        if not cfg.weight_mix_quant:
+            groups.append({"params": list(qlayer.let_parameters(cfg.use_shift)), "lr": cfg.let_lr})
+        groups.append({"params": list(qlayer.lwc_parameters()), "lr": cfg.lwc_lr})
+        optimizer = torch.optim.AdamW(groups, weight_decay=cfg.wd)
+        scaler = LossScaler("cuda" if dev.type == "cuda" else "cpu")
+        buf = None
+        steps_per_epoch = n_local // cfg.batch_size
+        loss_size_coef = cfg.loss_size_coef
+        for epoch in range(cfg.epochs):
+            if cfg.weight_mix_quant:
+                if epoch == round(cfg.epochs * 0.5):
+                    qlayer.set_hard_quant()
+                if epoch == round(cfg.epochs * 0.75):
+                    qlayer.round_nbits()
+                    loss_size_coef = 0
+            for j in range(steps_per_epoch):
+                i0 = j * cfg.batch_size
+                with traincast():
+                    qlayer.smooth_and_quant_temporary()
+                    out = qlayer(quant_inps[i0:i0 + cfg.batch_size], attention_mask=mask_batch, position_ids=position_ids)[0]
+                    loss = loss_func(fp_inps[i0:i0 + cfg.batch_size], out)
+                    if cfg.weight_mix_quant:
+                        ms, ts = qlayer.get_size_loss()
+                        loss = loss + loss_func(ms, ts) * loss_size_coef
+                if not math.isfinite(loss.item()):
+                    raise FloatingPointError(f"loss became {loss.item()} at epoch {epoch}, step {j}")
+                optimizer.zero_grad()
+                norm, buf = scaler(loss, optimizer, qlayer.omni_parameters(cfg.use_shift), dp, buf)
+                losses.append(float(loss.detach()))
+                norms.append(float(norm))
+                _free_act_stats(qlayer)
+            if logger is not None:
+                k = steps_per_epoch
+                logger.info(f"{layer_prefix} epoch {epoch} loss:{np.mean(losses[-k:])} norm:{np.mean(norms[-k:])}")
+        qlayer.clear_temp_variable()
+        del optimizer
+
+    finalize_layer(qlayer, quant_inps, attention_mask, cfg, dp, position_ids)
+    return {"losses": losses, "norms": norms, "indices": indices, "omni_state": qlayer.omni_state_dict()}
+
+
+def finalize_layer(qlayer, quant_inps, attention_mask, cfg: CalibConfig, dp: Optional[DPContext] = None, position_ids=None):
+    """In-place smoothing + weight quantization with the learned parameters, then the sequential
+    propagation pass over all samples (static activation statistics accumulate here, sample by
+    sample), scale registration and the switch to eval mode (reference omniquant.py:566-605)."""
+    dp = dp or DPContext()
+    n_local = quant_inps.shape[0]
+    n_total = cfg.nsamples
+    use_amp = not cfg.deactive_amp
+    if cfg.weight_mix_quant:
+        qlayer.round_nbits()
+    qlayer.smooth_and_quant_inplace()
+    _set_dp(qlayer, None)  # the propagation pass is replicated, not synchronised
+    if cfg.epochs <= 0:
+        qlayer.half()
+    cast = (torch.autocast("cuda", dtype=torch.float16) if (use_amp and cfg.epochs > 0) else nullcontext())
+    with torch.no_grad(), cast:
+        if dp.active:
+            a, _b = shard_range(n_total, dp.rank, dp.world)
+            tmp = torch.empty_like(quant_inps[0])
+            for j in range(n_total):
+                own = owner_of(j, n_total, dp.world)
+                if own == dp.rank:
+                    tmp.copy_(quant_inps[j - a])
+                broadcast_from(tmp, own, dp)
+                y = qlayer(tmp.unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]
+                if own == dp.rank:
+                    quant_inps[j - a] = y
+        else:
+            for j in range(n_local):
+                quant_inps[j] = qlayer(quant_inps[j].unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]
+    qlayer.register_scales_and_zeros()
+    if cfg.epochs > 0:
+        qlayer.half()
+    _set_eval(qlayer)
+
+
+def save_omni_parameters(omni_parameters: dict, output_dir: str):
+    """``{layer index: OrderedDict(name -> tensor)}`` in the reference's omni_parameters.pth format."""
+    os.makedirs(output_dir, exist_ok=True)
+    torch.save(omni_parameters, os.path.join(output_dir, "omni_parameters.pth"))
+
+
+def load_omni_parameters(path: str):
+    return torch.load(path, weights_only=True)

@@ -1,0 +1,112 @@
+"""Data-parallel plumbing for block calibration: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The path has exactly two exchange steps per optimizer step, both latency-bound small messages:
+  * one all-reduce (SUM, then / world) of all LWC/LET(/n_bits) gradients packed in one flat fp32 buffer;
+  * optionally, per activation-quantizer call, one MAX all-reduce of the packed [-min, max] channel
+    statistics so that every rank derives the scale of the GLOBAL batch (this makes W ranks with
+    batch 1 equal to the reference run with --batch_size W).
+Sample shards and weight-row shards need no communication.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class DPContext:
+    group: Optional[object] = None
+    rank: int = 0
+    world: int = 1
+    sync_stats: bool = False
+
+    @classmethod
+    def from_env(cls, sync_stats=False):
+        if dist.is_available() and dist.is_initialized():
+            return cls(dist.group.WORLD, dist.get_rank(), dist.get_world_size(), sync_stats)
+        return cls(None, 0, 1, False)
+
+    @property
+    def active(self):
+        return self.world > 1
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous, balanced [start, stop) of n items for this rank (first n % world ranks get one more)."""
+    base, extra = divmod(n, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def owner_of(index: int, n: int, world: int) -> int:
+    base, extra = divmod(n, world)
+    cut = extra * (base + 1)
+    if index < cut:
+        return index // (base + 1)
+    return extra + (index - cut) // base if base else world - 1
+
+
+def allreduce_mean_grads(params: Iterable[torch.nn.Parameter], ctx: DPContext, buf: Optional[torch.Tensor] = None):
+    """Average the gradients of ``params`` across ranks with ONE collective on a packed fp32 buffer.
+    Parameters without a gradient contribute zeros (and receive the mean of the others)."""
+    if not ctx.active:
+        return buf
+    params = [p for p in params]
+    if not params:
+        return buf
+    n = sum(p.numel() for p in params)
+    dev = params[0].device
+    if buf is None or buf.numel() != n or buf.device != dev:
+        buf = torch.empty(n, dtype=torch.float32, device=dev)
+    off = 0
+    for p in params:
+        k = p.numel()
+        if p.grad is None:
+            buf[off:off + k].zero_()
+        else:
+            buf[off:off + k].copy_(p.grad.reshape(-1))
+        off += k
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
+    buf.div_(ctx.world)
+    off = 0
+    for p in params:
+        k = p.numel()
+        g = buf[off:off + k].reshape(p.shape).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += k
+    return buf
+
+
+def allreduce_minmax(cmin: torch.Tensor, cmax: torch.Tensor, ctx: DPContext):
+    """Global per-channel min/max with one MAX all-reduce of [-min, max] (float32 vectors, in place)."""
+    if not ctx.active:
+        return cmin, cmax
+    packed = torch.cat((-cmin, cmax))
+    dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=ctx.group)
+    c = cmin.numel()
+    cmin.copy_(-packed[:c])
+    cmax.copy_(packed[c:])
+    return cmin, cmax
+
+
+def broadcast_from(t: torch.Tensor, src: int, ctx: DPContext):
+    if ctx.active:
+        dist.broadcast(t, src=src, group=ctx.group)
+    return t
+
+
+def shard_weight_rows(weights: List[torch.Tensor], ctx: DPContext):
+    """Output-channel shards of a list of [O, I] matrices for this rank: (row slice, view) pairs.
+    Row-wise quantizers treat every output row independently, so shards need no exchange."""
+    out = []
+    for w in weights:
+        a, b = shard_range(w.shape[0], ctx.rank, ctx.world)
+        out.append((slice(a, b), w[a:b]))
+    return out

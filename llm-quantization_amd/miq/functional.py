@@ -141,11 +141,14 @@ def colstat_chunks(R: int, C: int, dtype) -> int:
     return int(L.lib().miq_colstat_chunks(L.i64(R), L.i64(C), L.i32(L._DT[dtype])))
 
 
-def act_calibrate(x2d, n_bits: int, metric: str, layout: ClusterLayout, cached_min=None, cached_max=None, idx=None):
+def act_calibrate(x2d, n_bits: int, metric: str, layout: ClusterLayout, cached_min=None, cached_max=None, idx=None,
+                  dp=None):
     """Statistics pass + cluster merge + scale.  x2d is [R, C] contiguous.
 
     Returns dict(scale, zp, rzp, cmin, cmax: [C] in x's dtype; chan_min, chan_max: [C] float32
     per-channel statistics before the cluster merge, needed by the backward pass).
+    ``dp``: a miq.dist.DPContext with sync_stats=True makes the statistics those of the global batch
+    (one MAX all-reduce of the packed [-min, max] vectors).
     """
     dev = L.check_gpu(x2d, cached_min, cached_max, idx)
     R, C = x2d.shape
@@ -159,12 +162,24 @@ def act_calibrate(x2d, n_bits: int, metric: str, layout: ClusterLayout, cached_m
     with torch.cuda.device(dev):
         L.call("miq_colstat_minmax", L.ptr(x2d), L.i64(R), L.i64(C), L.ptr(part[0]), L.ptr(part[1]), L.i32(nchunk),
                L.i32(code), st)
-        L.call("miq_cluster_scale", L.ptr(part[0]), L.ptr(part[1]), L.i32(nchunk), L.i64(C), L.ptr(idx),
+        fold = nchunk
+        if dp is not None and dp.active and dp.sync_stats:
+            from .dist import allreduce_minmax
+            cm = part[0, :nchunk].amin(0)
+            cx = part[1, :nchunk].amax(0)
+            if idx is not None:
+                cm, cx = cm[idx.long()], cx[idx.long()]
+                idx = None
+            allreduce_minmax(cm, cx, dp)
+            part[0, 0].copy_(cm)
+            part[1, 0].copy_(cx)
+            fold = 1
+        L.call("miq_cluster_scale", L.ptr(part[0]), L.ptr(part[1]), L.i32(fold), L.i64(C), L.ptr(idx),
                L.ptr(cached_min), L.ptr(cached_max), L.i32(1 if metric == "ema_minmax" else 0), L.ptr(layout.starts),
                L.i32(layout.n_clusters), L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(outs[0]), L.ptr(outs[1]),
                L.ptr(outs[2]), L.ptr(outs[3]), L.ptr(outs[4]), L.i32(code), st)
     return {"cmin": outs[0], "cmax": outs[1], "scale": outs[2], "zp": outs[3], "rzp": outs[4],
-            "chan_min": part[0, nchunk], "chan_max": part[1, nchunk]}
+            "chan_min": part[0, fold], "chan_max": part[1, fold]}
 
 
 def colquant_fwd(x2d, scale, rzp, n_bits: int, want_codes: bool = False):
@@ -178,8 +193,9 @@ def colquant_fwd(x2d, scale, rzp, n_bits: int, want_codes: bool = False):
     return out, codes
 
 
-def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None):
-    """route = (chan_min, chan_max, kmin, kmax, layout) enables the min/max routing (calibration mode)."""
+def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
+    """route = (chan_min, chan_max, kmin, kmax, layout) enables the min/max routing (calibration mode).
+    With a stats-synchronised DPContext the per-channel sums are all-reduced between the two phases."""
     dev = L.check_gpu(g2d, x2d, scale, rzp)
     R, C = x2d.shape
     dx = torch.empty_like(x2d)
@@ -191,9 +207,18 @@ def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None):
                 L.i32(layout.n_clusters), L.i64(layout.covered), L.ptr(ws))
     else:
         args = (L.ptr(None),) * 5 + (L.i32(0), L.i64(0), L.ptr(None))
+    tail = (L.i32(nchunk), L.ptr(dx), L.i64(R), L.i64(C), L.i32(int(n_bits)))
+    code, st = L.i32(L.dtype_code(x2d)), L.stream_of(x2d)
     with torch.cuda.device(dev):
-        L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, L.i32(nchunk), L.ptr(dx),
-               L.i64(R), L.i64(C), L.i32(int(n_bits)), L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
+        if route is not None and dp is not None and dp.active and dp.sync_stats:
+            import torch.distributed as tdist
+            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(1), code, st)
+            sums = ws[:3 * nchunk * C].view(3, nchunk, C)[:, 0, :].contiguous()
+            tdist.all_reduce(sums, group=dp.group)
+            ws[:3 * nchunk * C].view(3, nchunk, C)[:, 0, :].copy_(sums)
+            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(2), code, st)
+        else:
+            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(0), code, st)
     return dx
 
 
@@ -249,10 +274,11 @@ class ActCalibFQ(torch.autograd.Function):
     function of x, so the backward routes the scale gradient to the extreme elements."""
 
     @staticmethod
-    def forward(ctx, x, n_bits, metric, layout, cached_min, cached_max, holder):
+    def forward(ctx, x, n_bits, metric, layout, cached_min, cached_max, holder, dp=None):
         x = x.contiguous()
         x2 = x.reshape(-1, x.shape[-1])
-        st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max)
+        st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max, dp=dp)
+        ctx.dp = dp
         out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
         holder.update(st)
         ctx.fresh = cached_min is None
@@ -268,8 +294,8 @@ class ActCalibFQ(torch.autograd.Function):
             raise L.MiqError("backward through cached activation statistics is not defined: call free() on the "
                              "quantizer after every optimizer step (the calibration loop does)")
         dx = colquant_bwd(g.contiguous().reshape(x2.shape), x2, s, z, ctx.n_bits,
-                          route=(chan_min, chan_max, kmin, kmax, ctx.layout))
-        return dx.reshape(g.shape), None, None, None, None, None, None
+                          route=(chan_min, chan_max, kmin, kmax, ctx.layout), dp=ctx.dp)
+        return dx.reshape(g.shape), None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

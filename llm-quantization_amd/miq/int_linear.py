@@ -30,9 +30,12 @@ class QuantLinear(nn.Module):
         super().__init__()
         self.fwd_kwargs = dict()
         self.fwd_func = TF.linear
-        self.register_buffer("weight", org_module.weight)
+        # plain tensors sharing the original storage: a buffer that is still an nn.Parameter would turn
+        # `temp_weight = weight` into a parameter registration (the reference avoids that by casting
+        # the block .half() then .float(), which strips the Parameter type as a side effect)
+        self.register_buffer("weight", org_module.weight.detach())
         if org_module.bias is not None:
-            self.register_buffer("bias", org_module.bias)
+            self.register_buffer("bias", org_module.bias.detach())
         else:
             self.bias = None
         self.in_features = org_module.in_features

@@ -79,6 +79,7 @@ class UniformAffineQuantizer(nn.Module):
         self.enable = True
         self.group_size = group_size
         self._vec = None  # per-channel [C] copies of (scale, rzp) for the kernels
+        self.dp = None    # optional miq.dist.DPContext: global-batch statistics under data parallelism
 
     # ------------------------------------------------------------------ small API surface
     def change_n_bits(self, n_bits):
@@ -196,7 +197,7 @@ class UniformAffineQuantizer(nn.Module):
         layout, kind = self._layout(x)
         cmin, cmax = self._cached_vectors(x)
         holder = {}
-        out = F.ActCalibFQ.apply(x, self.n_bits, self.metric, layout, cmin, cmax, holder)
+        out = F.ActCalibFQ.apply(x, self.n_bits, self.metric, layout, cmin, cmax, holder, self.dp)
         self._publish(x, holder, kind)
         return out
 
@@ -205,7 +206,7 @@ class UniformAffineQuantizer(nn.Module):
         layout, kind = self._layout(x)
         cmin, cmax = self._cached_vectors(x)
         xc = x.detach().contiguous()
-        st = F.act_calibrate(xc.reshape(-1, x.shape[-1]), self.n_bits, self.metric, layout, cmin, cmax)
+        st = F.act_calibrate(xc.reshape(-1, x.shape[-1]), self.n_bits, self.metric, layout, cmin, cmax, dp=self.dp)
         self._publish(x, st, kind)
 
     def _eval_vectors(self, x):

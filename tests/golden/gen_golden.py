@@ -536,6 +536,7 @@ def main():
     ref = import_reference(args.ref)
     fams = {"uniform": gen_uniform, "mix2": gen_mix2, "exp1": gen_exp1, "exp2": gen_exp2, "mix": gen_mix,
             "act": gen_act, "reorder": gen_reorder}
+    fams["block"] = lambda _ref: gen_block(args.ref)
     for fam, fn in fams.items():
         if args.only and fam not in args.only.split(","):
             continue
@@ -543,6 +544,185 @@ def main():
         path = os.path.join(HERE, f"{fam}.pt")
         torch.save(cases, path)
         print(f"{fam}: {len(cases)} cases -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+
+# ---------------------------------------------------------------------------------------------
+# block-level calibration fixture: the reference's QuantOPTDecoderLayer + Reorder + the training
+# loop of omniquant() (quantize/omniquant.py:399-605, restated here only as far as control flow goes;
+# every numerical step is the reference's own code) on a tiny OPT-shaped block, fp32 path.
+# ---------------------------------------------------------------------------------------------
+def gen_block(ref_root):
+    import tempfile
+    import types as _t
+
+    for name in ("auto_gptq", "auto_gptq.nn_modules", "auto_gptq.nn_modules.qlinear", "auto_gptq.nn_modules.qlinear.qlinear_cuda"):
+        sys.modules.setdefault(name, _t.ModuleType(name))
+    from models.int_opt_layer import QuantOPTDecoderLayer
+    from quantize import omniquant as OQ
+    from quantize import reorder_utils as RU
+    from quantize.int_linear import QuantLinear
+    from quantize.int_matmul import QuantMatMul
+    import utils as ref_utils
+
+    H, Fd, heads, T, N, epochs = 64, 256, 4, 32, 4, 2
+    wbits, abits = 4, 4
+    g = synth.gen(91)
+
+    def lin(i, o):
+        l = torch.nn.Linear(i, o)
+        with torch.no_grad():
+            l.weight.copy_(torch.randn(o, i, generator=g) * 0.08)
+            l.bias.copy_(torch.randn(o, generator=g) * 0.05)
+        return l
+
+    def ln(c):
+        l = torch.nn.LayerNorm(c)
+        with torch.no_grad():
+            l.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            l.bias.copy_(torch.randn(c, generator=g) * 0.1)
+        return l
+
+    src = torch.nn.Module()
+    src.self_attn = torch.nn.Module()
+    src.self_attn.q_proj, src.self_attn.k_proj = lin(H, H), lin(H, H)
+    src.self_attn.v_proj, src.self_attn.out_proj = lin(H, H), lin(H, H)
+    src.self_attn_layer_norm, src.final_layer_norm = ln(H), ln(H)
+    src.fc1, src.fc2 = lin(H, Fd), lin(Fd, H)
+    src = src.half()  # the reference's harness requirement: buffers must lose their Parameter type on .float()
+
+    args = _t.SimpleNamespace(
+        weight_quant_params={"n_bits": wbits, "per_channel_axes": [0], "symmetric": False, "dynamic_method": "per_channel",
+                             "group_size": None, "lwc": True, "dynamic": True, "metric": "minmax", "target_bit": wbits},
+        act_quant_params={"n_bits": abits, "per_channel_axes": [], "symmetric": False, "dynamic_method": "per_cluster",
+                          "dynamic": False, "metric": "ema_minmax"},
+        p_quant_params={"n_bits": 16, "metric": "fix0to1"},
+        weight_exp_quant=False, weight_mix_quant=False, weight_mix2_quant=False, layer_num=0,
+        let=True, alpha=0.5, let_lr=5e-3, lwc_lr=1e-2, wd=0.0, batch_size=1, nsamples=N, epochs=epochs)
+    args.q_quant_params = dict(args.act_quant_params)
+    args.k_quant_params = dict(args.act_quant_params)
+    args.v_quant_params = dict(args.act_quant_params)
+    config = _t.SimpleNamespace(hidden_size=H, num_attention_heads=heads, attention_dropout=0.0, enable_bias=True,
+                                do_layer_norm_before=True, dropout=0.0, ffn_dim=Fd)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "grads_results_uniform"))
+        torch.save(torch.full((8192,), 3.0), os.path.join(td, "grads_results_uniform", "layer0_nbits.pt"))
+        os.chdir(td)
+        try:
+            qlayer = QuantOPTDecoderLayer(config, src, args)
+        finally:
+            os.chdir(cwd)
+    d = {"meta": {"H": H, "F": Fd, "heads": heads, "T": T, "N": N, "epochs": epochs, "wbits": wbits, "abits": abits,
+                  "clusters": {"R1": 8, "R2": 2, "R3": 2, "R4": 8, "R5": 8}}}
+    a = src.self_attn
+    for n, m in (("q", a.q_proj), ("k", a.k_proj), ("v", a.v_proj), ("o", a.out_proj), ("fc1", src.fc1), ("fc2", src.fc2)):
+        d[f"w_{n}"] = m.weight.detach().float().clone()
+        d[f"w_{n}_b"] = m.bias.detach().float().clone()
+    for n, m in (("ln1", src.self_attn_layer_norm), ("ln2", src.final_layer_norm)):
+        d[f"w_{n}_w"] = m.weight.detach().float().clone()
+        d[f"w_{n}_b"] = m.bias.detach().float().clone()
+
+    # synthetic, tie-free channel statistics for Reorder (hooks are pinned separately)
+    def stats(c):
+        mn = -(torch.randint(1, 1024, (c,), generator=g).float() / 256)
+        mx = (1 + torch.randperm(c, generator=g).float() / 256) + mn
+        return mx, mn
+
+    RU.oc_maxmin_dict.clear()
+    RU.ic_maxmin_dict.clear()
+    for name, c in (("self_attn_layer_norm", H), ("self_attn.q_proj", H), ("self_attn.k_proj", H), ("final_layer_norm", H)):
+        RU.oc_maxmin_dict[name] = stats(c)
+        d[f"stat_oc_{name}_max"], d[f"stat_oc_{name}_min"] = RU.oc_maxmin_dict[name]
+    for name, c in (("self_attn.out_proj", H), ("fc2", Fd)):
+        RU.ic_maxmin_dict[name] = stats(c)
+        d[f"stat_ic_{name}_max"], d[f"stat_ic_{name}_min"] = RU.ic_maxmin_dict[name]
+    indices = OQ.Reorder(qlayer, config, True, True, True, True, True, d["meta"]["clusters"], "cpu")
+    for k, v in indices.items():
+        d[f"index_{k}"] = v.clone()
+
+    inps = synth.activation((N, T, H), 92) * 0.5
+    d["inps"] = inps.clone()
+    mask = torch.full((T, T), torch.finfo(torch.float32).min).triu(1).view(1, 1, T, T)
+    d["mask"] = mask.clone()
+    prefix = "model.decoder.layers.0"
+    act_scales, act_shifts = {}, {}
+    for name, c in (("self_attn.q_proj", H), ("self_attn.out_proj", H), ("fc1", H)):
+        act_scales[f"{prefix}.{name}"] = torch.rand(c, generator=g) * 3 + 0.2
+        act_shifts[f"{prefix}.{name}"] = torch.randn(c, generator=g) * 0.1
+        d[f"act_scale_{name}"], d[f"act_shift_{name}"] = act_scales[f"{prefix}.{name}"], act_shifts[f"{prefix}.{name}"]
+
+    quant_inps, fp_inps = inps.clone(), inps.clone()
+    qlayer.set_quant_state(weight_quant=False, act_quant=False)
+    with torch.no_grad():
+        # the reference runs this pass with fp16 parameters under CUDA autocast and casts to fp32
+        # afterwards (omniquant.py:399-404,464); on CPU the cast has to come first
+        qlayer.float()
+        for j in range(N):
+            fp_inps[j] = qlayer(fp_inps[j].unsqueeze(0), attention_mask=mask)[0]
+    d["fp_out"] = fp_inps.clone()
+    qlayer.set_quant_state(weight_quant=False, act_quant=True)
+    qlayer.let = True
+    dtype = torch.float32
+    pairs = {"q_proj": "qkv", "out_proj": "out", "fc1": "fc1"}
+    rmap = {"q_proj": "R1", "out_proj": "R3", "fc1": "R4"}
+    qlayer.register_parameter("qkt_smooth_scale", torch.nn.Parameter(torch.ones(H, dtype=dtype)))
+    for name, module in qlayer.named_modules():
+        if isinstance(module, QuantLinear):
+            for key in pairs:
+                if key in name:
+                    act = torch.index_select(act_scales[f"{prefix}.{name}"].clamp(min=1e-5), 0, indices[rmap[key]])
+                    weight = module.weight.max(dim=0)[0].clamp(min=1e-5)
+                    scale = (act.pow(args.alpha) / weight.pow(1 - args.alpha)).clamp(min=1e-5)
+                    shift = torch.index_select(act_shifts[f"{prefix}.{name}"], 0, indices[rmap[key]])
+                    qlayer.register_parameter(f"{pairs[key]}_smooth_shift", torch.nn.Parameter(shift))
+                    qlayer.register_parameter(f"{pairs[key]}_smooth_scale", torch.nn.Parameter(scale))
+    with torch.no_grad():
+        qlayer.float()
+    optimizer = torch.optim.AdamW([{"params": qlayer.let_parameters(True), "lr": args.let_lr},
+                                   {"params": qlayer.lwc_parameters(), "lr": args.lwc_lr}], weight_decay=args.wd)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss_scaler = ref_utils.NativeScalerWithGradNormCount()
+    loss_func = torch.nn.MSELoss()
+    losses, norms = [], []
+    for _epoch in range(epochs):
+        for j in range(N):
+            qlayer.smooth_and_quant_temporary()
+            out = qlayer(quant_inps[j:j + 1], attention_mask=mask)[0]
+            loss = loss_func(fp_inps[j:j + 1], out)
+            optimizer.zero_grad()
+            norm = loss_scaler(loss, optimizer, parameters=qlayer.omni_parameters(True))
+            losses.append(loss.detach().clone())
+            norms.append(norm.detach().clone())
+            for _n, m in qlayer.named_modules():
+                if isinstance(m, QuantLinear) and not m.disable_input_quant:
+                    m.act_quantizer.free()
+                if isinstance(m, QuantMatMul):
+                    m.x1_quantizer.free()
+                    m.x2_quantizer.free()
+    qlayer.clear_temp_variable()
+    d["losses"], d["norms"] = torch.stack(losses), torch.stack(norms)
+    for k, v in qlayer.omni_state_dict().items():
+        d[f"omni_fp32_{k}"] = v.detach().clone()
+    qlayer.smooth_and_quant_inplace()
+    with torch.no_grad():
+        for j in range(N):
+            quant_inps[j] = qlayer(quant_inps[j].unsqueeze(0), attention_mask=mask)[0]
+    d["quant_out"] = quant_inps.clone()
+    for name, m in qlayer.named_modules():
+        if isinstance(m, QuantLinear) and not m.disable_input_quant:
+            d[f"actscale_{name}"] = m.act_quantizer.scale.detach().clone()
+            d[f"actrzp_{name}"] = m.act_quantizer.round_zero_point.detach().clone()
+        if isinstance(m, QuantLinear):
+            d[f"wq_{name}"] = m.weight.detach().clone()
+    qlayer.register_scales_and_zeros()
+    qlayer.half()
+    d["omni_keys"] = list(qlayer.omni_state_dict().keys())
+    RU.oc_maxmin_dict.clear()
+    RU.ic_maxmin_dict.clear()
+    return {"opt_tiny_w4a4_reorder": d}
 
 
 if __name__ == "__main__":
