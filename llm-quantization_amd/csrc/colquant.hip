@@ -179,6 +179,22 @@ __global__ void __launch_bounds__(256) k_cluster_scale(ScaleArgs<T> a) {
     }
 }
 
+// Level of one element for a per-channel scale that is known to be finite and positive (the
+// calibrated scale is clamped to [1e-5, 1e4]; a NaN scale propagates through either path).
+template <typename T>
+__device__ __forceinline__ float col_div(float x, float s, float rs);
+template <> __device__ __forceinline__ float col_div<float>(float x, float s, float) { return x / s; }
+template <> __device__ __forceinline__ float col_div<__half>(float x, float s, float rs) {
+    const float q0 = x * rs;
+    const float e = __builtin_fmaf(-q0, s, x);   // exact residual: see Divisor<__half>
+    return __half2float(__float2half(__builtin_fmaf(e, rs, q0)));
+}
+template <typename T>
+__device__ __forceinline__ float col_level(float x, float s, float rs, float z, bool exact_int) {
+    const float xi = rint_ste(col_div<T>(x, s, rs)) + z;
+    return exact_int ? xi : rnd<T>(xi);
+}
+
 // ---------------------------------------------------------------------------------------------
 // quantize-dequantize with per-channel parameters
 // ---------------------------------------------------------------------------------------------
@@ -192,23 +208,29 @@ k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
-    float s[VEC], z[VEC];
+    float s[VEC], z[VEC], rs[VEC];
+    bool ok = true;
     {
         Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { s[e] = to_f<T>(ps.e[e]); z[e] = to_f<T>(pz.e[e]); }
+        for (int e = 0; e < VEC; ++e) {
+            s[e] = to_f<T>(ps.e[e]);
+            z[e] = to_f<T>(pz.e[e]);
+            rs[e] = 1.0f / s[e];
+            ok = ok && ints_exact<T>(z[e], qmax);
+        }
     }
+    // wave-uniform: every integer intermediate of this wave's channels is exact in T
+    const bool exact_int = __all(ok);
     auto body = [&](const Pack<T, VEC>& a, long long r) {
         Pack<T, VEC> o;
         Pack<uint8_t, VEC> cd;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const float q = rnd<T>(to_f<T>(a.e[e]) / s[e]);
-            const float rr = rintf(q);
-            const float xi = rnd<T>(rnd<T>(rnd<T>(rr - q) + q) + z[e]);
+            const float xi = col_level<T>(to_f<T>(a.e[e]), s[e], rs[e], z[e], exact_int);
             const float xc = clampf(xi, 0.f, qmax);
-            o.e[e] = from_f<T>(rnd<T>(xc - z[e]) * s[e]);
-            cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+            o.e[e] = from_f<T>(affine_dequant<T>(xc, s[e], z[e], exact_int));
+            if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
         }
         st_pack<T, VEC>(out + r * C + col0, o);
         if (codes) st_pack<uint8_t, VEC>(codes + r * C + col0, cd);

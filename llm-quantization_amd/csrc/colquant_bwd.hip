@@ -15,11 +15,20 @@
 
 namespace miq {
 
+template <typename T> __device__ __forceinline__ float cdiv(float x, float s, float rs);
+template <> __device__ __forceinline__ float cdiv<float>(float x, float s, float) { return x / s; }
+template <> __device__ __forceinline__ float cdiv<__half>(float x, float s, float rs) {
+    // exact IEEE quotient of two fp16 values from one Newton correction (see Divisor<__half>); the
+    // calibrated scale is clamped to [1e-5, 1e4], so it is never 0 or inf
+    const float q0 = x * rs;
+    const float e = __builtin_fmaf(-q0, s, x);
+    return __half2float(__float2half(__builtin_fmaf(e, rs, q0)));
+}
+
 template <typename T>
-__device__ __forceinline__ void fq_terms(float xv, float s, float z, float qmax, float& q, bool& m, float& xd) {
-    q = rnd<T>(xv / s);
-    const float rr = rintf(q);
-    const float xi = rnd<T>(rnd<T>(rnd<T>(rr - q) + q) + z);
+__device__ __forceinline__ void fq_terms(float xv, float s, float rs, float z, float qmax, float& q, bool& m, float& xd) {
+    q = cdiv<T>(xv, s, rs);
+    const float xi = rnd<T>(rint_ste(q) + z);
     m = (xi >= 0.f) && (xi <= qmax);
     xd = rnd<T>(clampf(xi, 0.f, qmax) - z);
 }
@@ -41,11 +50,12 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = acc[2][e] = 0.f;
     if (valid) {
-        float s[VEC], z[VEC], cmn[VEC], cmx[VEC];
+        float s[VEC], rs[VEC], z[VEC], cmn[VEC], cmx[VEC];
         Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             s[e] = to_f<T>(ps.e[e]);
+            rs[e] = 1.0f / s[e];
             z[e] = to_f<T>(pz.e[e]);
             cmn[e] = chan_min[col0 + e];
             cmx[e] = chan_max[col0 + e];
@@ -56,7 +66,7 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
                 const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
                 float q, xd;
                 bool m;
-                fq_terms<T>(xv, s[e], z[e], qmax, q, m, xd);
+                fq_terms<T>(xv, s[e], rs[e], z[e], qmax, q, m, xd);
                 acc[0][e] += gv * (xd - (m ? q : 0.f));
                 acc[1][e] += (xv == cmx[e]) ? 1.f : 0.f;
                 acc[2][e] += (xv == cmn[e]) ? 1.f : 0.f;
@@ -179,11 +189,12 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
-    float s[VEC], z[VEC], cmn[VEC], cmx[VEC], hmn[VEC], hmx[VEC];
+    float s[VEC], rs[VEC], z[VEC], cmn[VEC], cmx[VEC], hmn[VEC], hmx[VEC];
     Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         s[e] = to_f<T>(ps.e[e]);
+        rs[e] = 1.0f / s[e];
         z[e] = to_f<T>(pz.e[e]);
         if (ROUTE) {
             cmn[e] = chan_min[col0 + e];
@@ -199,8 +210,9 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
             const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
             float q, xd;
             bool m;
-            fq_terms<T>(xv, s[e], z[e], qmax, q, m, xd);
-            float d = m ? (gv * s[e]) / s[e] : 0.f;
+            fq_terms<T>(xv, s[e], rs[e], z[e], qmax, q, m, xd);
+            // fp32 reproduces autograd's (g*s)/s; for fp16 gradients the plain g is within their rounding
+            float d = m ? (sizeof(T) == 4 ? (gv * s[e]) / s[e] : gv) : 0.f;
             if (ROUTE) {
                 if (xv == cmx[e]) d += hmx[e];
                 if (xv == cmn[e]) d += hmn[e];

@@ -67,6 +67,66 @@ template <typename T> __device__ __forceinline__ float sigmoid_t(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// x / s rounded to T, for a divisor that is reused many times.
+//   float: plain IEEE division.
+//   half : x and s carry 11-bit significands, so one Newton correction on a product with the
+//          correctly rounded reciprocal gives EXACTLY the IEEE fp32 quotient: the residual
+//          e = x - q0*s is exact in an fma, and the true quotient of two 11-bit numbers can never sit
+//          within 2^-36 of an fp32 rounding boundary.  3 VALU ops instead of the ~12 of a full
+//          division; divisors that are 0, inf or NaN take the plain division.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Divisor;
+template <> struct Divisor<float> {
+    float s;
+    __device__ __forceinline__ explicit Divisor(float s_) : s(s_) {}
+    __device__ __forceinline__ float div(float x) const { return x / s; }
+};
+template <> struct Divisor<__half> {
+    float s, rs;
+    bool fast;
+    __device__ __forceinline__ explicit Divisor(float s_) : s(s_), rs(1.0f / s_) {
+        const float a = fabsf(s_);
+        fast = (a > 0.f) && (a < __builtin_inff());
+    }
+    __device__ __forceinline__ float div(float x) const {
+        float q;
+        if (fast) {
+            const float q0 = x * rs;
+            const float e = __builtin_fmaf(-q0, s, x);
+            q = __builtin_fmaf(e, rs, q0);
+        } else {
+            q = x / s;
+        }
+        return __half2float(__float2half(q));
+    }
+};
+
+// round-to-nearest-even with the straight-through form (r - q) + q of the reference: equal to r for
+// finite q, NaN for +-inf and NaN.  (r - q) and the sum are exact in every dtype, so no rounding step.
+__device__ __forceinline__ float rint_ste(float q) {
+    return (fabsf(q) == __builtin_inff()) ? __builtin_nanf("") : rintf(q);
+}
+
+// The affine quantization level of one element: clamp(round(x/s) + zp, 0, qmax) and the dequantized
+// value (level - zp) * s, with the per-op rounding of T.  `exact_int` tells that |zp| + qmax <= 2048 and
+// qmax < 2048, i.e. every integer intermediate is exactly representable in fp16 (always true for fp32).
+template <typename T>
+__device__ __forceinline__ float affine_level(float x, const Divisor<T>& dv, float zp, bool exact_int) {
+    const float xi = rint_ste(dv.div(x)) + zp;
+    return exact_int ? xi : rnd<T>(xi);
+}
+template <typename T>
+__device__ __forceinline__ float affine_dequant(float level_clamped, float s, float zp, bool exact_int) {
+    const float d = level_clamped - zp;
+    return (exact_int ? d : rnd<T>(d)) * s;  // the product is rounded by the store conversion
+}
+template <typename T> __device__ __forceinline__ bool ints_exact(float zp, float qmax);
+template <> __device__ __forceinline__ bool ints_exact<float>(float, float) { return true; }
+template <> __device__ __forceinline__ bool ints_exact<__half>(float zp, float qmax) {
+    return (fabsf(zp) + qmax <= 2048.f) && (qmax < 2048.f);
+}
+
+// ---------------------------------------------------------------------------------------------
 // team reductions.  A "team" is TEAM consecutive threads that own one quantization row.
 // TEAM <= 64: shuffle only (team lies inside one wave).  TEAM > 64: TEAM == blockDim.x, LDS exchange.
 // ---------------------------------------------------------------------------------------------

@@ -50,9 +50,9 @@ struct Exp2Elem {
 };
 
 template <typename T>
-__device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c) {
+__device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c, const Divisor<T>& dv) {
     Exp2Elem r;
-    const float q = rnd<T>(xv / c.s);
+    const float q = dv.div(xv);
     r.sign = sgnf(q);
     const float a0 = fabsf(q);
     r.is_zero = a0 < 0.5f;
@@ -83,13 +83,14 @@ k_exp2_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
+    const Divisor<T> dv(c.s);
     if (lane == 0) scale_out[row] = from_f<T>(c.s);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
         Pack<T, VEC> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_elem<T>(to_f<T>(x.v[k].e[e]), c).signed_lvl * c.s);
+        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_elem<T>(to_f<T>(x.v[k].e[e]), c, dv).signed_lvl * c.s);
         st_pack<T, VEC>(out + base + x.offset(k), o);
     }
 }
@@ -118,6 +119,7 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     float rmin, rmax;
     row_minmax(x, padded, lds, rmin, rmax);
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
+    const Divisor<T> dv(c.s);
     auto grad_q = [&](float gv, const Exp2Elem& el) {
         float gq = gv * c.s;
         if (el.sign == -1.f) gq = -gq;
@@ -133,7 +135,7 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-            const Exp2Elem el = exp2_elem<T>(xv, c);
+            const Exp2Elem el = exp2_elem<T>(xv, c, dv);
             const float gqq = grad_q(gv, el);
             acc[0] += gv * el.signed_lvl + gqq * (-xv / (c.s * c.s));
             acc[1] += (xv == rmax) ? 1.f : 0.f;
@@ -160,7 +162,7 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-                float d = grad_q(gv, exp2_elem<T>(xv, c)) / c.s;
+                float d = grad_q(gv, exp2_elem<T>(xv, c, dv)) / c.s;
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);
@@ -201,11 +203,11 @@ struct Exp1Elem {
 };
 
 template <typename T>
-__device__ __forceinline__ Exp1Elem exp1_elem(float xv, const Exp1Ctx& c) {
+__device__ __forceinline__ Exp1Elem exp1_elem(float xv, const Exp1Ctx& c, const Divisor<T>& dv) {
     Exp1Elem r;
     r.v = c.has_mid ? rnd<T>(xv - c.mid) : xv;
     r.sign = sgnf(r.v);
-    r.u = rnd<T>(r.v / c.s);
+    r.u = dv.div(r.v);
     r.mag = clampf(fabsf(r.u), rnd<T>(kClipLo), kClipHi);
     const float l = rnd<T>(log2f(r.mag));
     r.lround = rnd<T>(rnd<T>(rintf(l) - l) + l);
@@ -236,6 +238,7 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
+    const Divisor<T> dv(c.s);
     if (lane == 0) {
         scale_out[row] = from_f<T>(c.s);
         if (mid_out) mid_out[row] = from_f<T>(c.mid);
@@ -245,7 +248,7 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
         if (!x.has(k)) continue;
         Pack<T, VEC> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_out<T>(exp1_elem<T>(to_f<T>(x.v[k].e[e]), c), c));
+        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_out<T>(exp1_elem<T>(to_f<T>(x.v[k].e[e]), c, dv), c));
         st_pack<T, VEC>(out + base + x.offset(k), o);
     }
 }
@@ -273,6 +276,7 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     float rmin, rmax;
     row_minmax(x, padded, lds, rmin, rmax);
     const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
+    const Divisor<T> dv(c.s);
     const float alo = rnd<T>(kClipLo);
     auto d_u = [&](float gv, const Exp1Elem& el) {
         const bool live = (el.lround >= c.e_lo) && (el.lround <= 0.f) && (fabsf(el.u) >= alo) && (fabsf(el.u) <= kClipHi);
@@ -286,7 +290,7 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-            const Exp1Elem el = exp1_elem<T>(xv, c);
+            const Exp1Elem el = exp1_elem<T>(xv, c, dv);
             const float du = d_u(gv, el);
             acc[0] += gv * (el.p * el.sign) + du * (-el.v / (c.s * c.s));
             acc[1] += gv - du / c.s;
@@ -320,7 +324,7 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-                float d = d_u(gv, exp1_elem<T>(xv, c)) / c.s;
+                float d = d_u(gv, exp1_elem<T>(xv, c, dv)) / c.s;
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);

@@ -71,15 +71,16 @@ __device__ __forceinline__ UniCtx uniform_ctx(const UniArgs<T>& a, long long row
     return c;
 }
 
-// round(x/s) with the straight-through form (r - q) + q: identical to r for finite q, NaN for +-inf
+// level before clamping: round_ste(x/s) + zp
 template <typename T>
-__device__ __forceinline__ float quant_level(float x, const UniCtx& c) {
-    const float q = rnd<T>(x / c.s);
-    const float r = rintf(q);
-    const float xi = rnd<T>(rnd<T>(r - q) + q);
-    return rnd<T>(xi + c.rzp);
+__device__ __forceinline__ float quant_level(float x, const Divisor<T>& dv, const UniCtx& c, bool exact_int) {
+    return affine_level<T>(x, dv, c.rzp, exact_int);
 }
 
+// One row per team, one launch wave of blocks after the other: a persistent variant that prefetches
+// the team's next row while computing the current one was measured slower (the second register tile
+// costs more occupancy than the overlap returns), and so was a one-wave-per-row tiling without the
+// block barrier.
 template <typename T, int VEC, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
 k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out,
@@ -101,6 +102,8 @@ k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ sc
         scale_out[row] = from_f<T>(c.s);
         rzp_out[row] = from_f<T>(c.rzp);
     }
+    const Divisor<T> dv(c.s);
+    const bool exact_int = ints_exact<T>(c.rzp, c.qmax);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
@@ -108,10 +111,10 @@ k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ sc
         Pack<uint8_t, VEC> cd;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const float xi = quant_level<T>(to_f<T>(x.v[k].e[e]), c);
+            const float xi = quant_level<T>(to_f<T>(x.v[k].e[e]), dv, c, exact_int);
             const float xc = clampf(xi, 0.f, c.qmax);
-            o.e[e] = from_f<T>(rnd<T>(rnd<T>(xc - c.rzp) * c.s));
-            cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+            o.e[e] = from_f<T>(affine_dequant<T>(xc, c.s, c.rzp, exact_int));
+            if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
         }
         const long long off = base + x.offset(k);
         st_pack<T, VEC>(out + off, o);
@@ -120,7 +123,7 @@ k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ sc
 }
 
 // Backward.  With m = [0 <= round(x/s)+zp <= qmax] and xd = clamp(..) - zp:
-//   dx      = g*m                       (direct path; computed as (g*s)*m/s like autograd does)
+//   dx      = g*m                       (direct path)
 //   dS      = sum_row g*(xd - m*x/s)    (gradient reaching the scale)
 //   asym:   d_range = dS/qmax (masked by the scale clamp when it is active)
 //           d_xmax = d_range, d_xmin = -d_range
@@ -129,7 +132,9 @@ k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ sc
 //   and the row max/min elements of x receive d_xmax*su / d_xmin*sl, split evenly among ties
 //   (zero padding counts as a tie candidate and swallows its share).
 template <typename T, int VEC, int TEAM, int NV, bool WANT_DX>
-__global__ void __launch_bounds__(block_of<TEAM>())
+// register budget: >= 4 waves per SIMD (two 512-thread blocks per CU) except for the widest fp16 tiles,
+// whose 64 elements per thread would spill under that cap
+__global__ void __launch_bounds__(block_of<TEAM>(), (sizeof(T) == 2 && NV == 8 && TEAM < 1024) ? 2 : 4)
 k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx,
               T* __restrict__ d_up, T* __restrict__ d_low) {
     __shared__ float lds[64];
@@ -148,7 +153,11 @@ k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restri
     row_minmax(x, padded, lds, rmin, rmax);
     const UniCtx c = uniform_ctx<T>(a, row, rmin, rmax);
 
+    const Divisor<T> dv(c.s);
+    const bool exact_int = ints_exact<T>(c.rzp, c.qmax);
     float acc[3] = {0.f, 0.f, 0.f};  // dS, #elements == rmax, #elements == rmin
+    static_assert(NV * VEC <= 64, "mask of un-clamped elements is one 64-bit word");
+    unsigned long long inside = 0ull;  // bit k*VEC+e: the level of element (k, e) lies inside the grid
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
@@ -156,11 +165,12 @@ k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restri
         for (int e = 0; e < VEC; ++e) {
             const float xv = to_f<T>(x.v[k].e[e]);
             const float gv = to_f<T>(g.v[k].e[e]);
-            const float q = rnd<T>(xv / c.s);
-            const float xi = quant_level<T>(xv, c);
+            const float q = dv.div(xv);
+            const float xi = quant_level<T>(xv, dv, c, exact_int);
             const bool m = (xi >= 0.f) && (xi <= c.qmax);
             const float xd = clampf(xi, 0.f, c.qmax) - c.rzp;
             acc[0] += gv * (xd - (m ? q : 0.f));
+            inside |= (m ? 1ull : 0ull) << (k * VEC + e);
             if (WANT_DX) {
                 acc[1] += (xv == rmax) ? 1.f : 0.f;
                 acc[2] += (xv == rmin) ? 1.f : 0.f;
@@ -208,9 +218,9 @@ k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restri
             for (int e = 0; e < VEC; ++e) {
                 const float xv = to_f<T>(x.v[k].e[e]);
                 const float gv = to_f<T>(g.v[k].e[e]);
-                const float xi = quant_level<T>(xv, c);
-                const bool m = (xi >= 0.f) && (xi <= c.qmax);
-                float d = m ? (gv * c.s) / c.s : 0.f;
+                // straight-through: the gradient passes where the level was not clamped (autograd forms
+                // (g*s)/s here, which equals g to within one rounding)
+                float d = ((inside >> (k * VEC + e)) & 1ull) ? gv : 0.f;
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);
