@@ -177,7 +177,12 @@ class Workload:
         for name, fn in fams:
             seg.run(name, fn, timed)
         if world > 1:
-            torch.distributed.all_reduce(self.flat)
+            if os.environ.get("MIQ_BENCH_ONE_GPU") == "1":  # rehearsal: gloo reduces a host copy
+                host = self.flat.cpu()
+                torch.distributed.all_reduce(host)
+                self.flat.copy_(host)
+            else:
+                torch.distributed.all_reduce(self.flat)
             self.flat.div_(world)
 
 
@@ -234,11 +239,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # MIQ_BENCH_ONE_GPU=1 is a development aid: all ranks share GPU 0 and talk over gloo, which lets the
+    # N > 1 code path be rehearsed on a single-GPU box.  The real launch is one rank per GPU over RCCL.
+    rehearsal = os.environ.get("MIQ_BENCH_ONE_GPU") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device(dev))
+        if rehearsal:
+            import datetime
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            torch.distributed.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device(dev))
 
     wl = Workload(dev, seed=2 + 1000 * rank)
     seg = Segments()
