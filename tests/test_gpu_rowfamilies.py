@@ -222,3 +222,72 @@ def test_reorder_index_ties_are_stable_and_large():
     ref, _ = O.reorder_index(r, torch.zeros_like(r), 4, 64)
     assert torch.equal(idx, ref)
     assert torch.equal(torch.sort(idx).values, torch.arange(28672))
+
+
+# ------------------------------------------------------------------------------------ benchmark shapes vs the oracle
+@pytest.mark.parametrize("shape,bits", [((4096, 4096), 3), ((11008, 4096), 3), ((4096, 11008), 4), ((1024, 28672), 2)])
+def test_exp2_llama_shapes_vs_oracle(shape, bits):
+    """Llama-2-7B weight shapes (BASELINE configs[2]: W3A16 exponential quantizer, fwd + STE bwd)."""
+    x = synth.weight(shape[0], shape[1], 2)
+    up, low = synth.lwc_factors(shape[0], 3)
+    w = synth.grad_like(x, 4)
+    xg = x.clone().requires_grad_(True)
+    pu, pl = up.clone().requires_grad_(True), low.clone().requires_grad_(True)
+    r = O.exp2_row(xg, bits, pu, pl)
+    g = torch.autograd.grad((r.out * w).sum(), [xg, pu, pl])
+    su, sl = sig(up, low)
+    out, scale = F.rowquant_exp2_fwd(x.to(DEV), bits, su, sl, preactivated=True)
+    assert same(scale.cpu(), r.scale.detach())
+    nflip = check_exp_forward(x, r.scale.detach(), out, r.out.detach(), 2)
+    dx, d_su, d_sl = F.rowquant_exp2_bwd(w.to(DEV), x.to(DEV), bits, su, sl, preactivated=True)
+    if nflip == 0:
+        assert masked_rel(dx, g[0]) <= 4e-5
+        assert masked_rel(chain(d_su, su), g[1]) <= 2e-5 and masked_rel(chain(d_sl, sl), g[2]) <= 2e-5
+
+
+@pytest.mark.parametrize("shape,hard", [((5120, 5120), False), ((13824, 5120), True), ((1280, 13824), False)])
+def test_mix_llama13b_shapes_vs_oracle(shape, hard):
+    """Llama-2-13B weight shapes (BASELINE configs[3]: learnable per-output-channel bits), soft and hard phase."""
+    x = synth.weight(shape[0], shape[1], 5)
+    up, low = synth.lwc_factors(shape[0], 6)
+    nb = synth.mix_bits(shape[0], 3.0, 7)
+    w = synth.grad_like(x, 8)
+    xg = x.clone().requires_grad_(True)
+    pu, pl, pn = up.clone().requires_grad_(True), low.clone().requires_grad_(True), nb.clone().requires_grad_(True)
+    r = O.mix_row(xg, pn, False, pu, pl, None, hard, 0.0)
+    g = torch.autograd.grad((r.out * w).sum(), [xg, pn, pu, pl])
+    su, sl = sig(up, low)
+    nbd = nb.reshape(-1).to(DEV)
+    out = F.rowquant_mix_fwd(x.to(DEV), nbd, False, su, sl, 0, hard, 0.0, preactivated=True)
+    assert same(out.cpu(), r.out.detach())
+    dx, d_su, d_sl, d_n = F.rowquant_mix_bwd(w.to(DEV), x.to(DEV), nbd, False, su, sl, 0, hard, 0.0, preactivated=True)
+    assert masked_rel(dx, g[0]) <= 4e-5
+    assert masked_rel(d_n.reshape(-1, 1), g[1]) <= 4e-5
+    assert masked_rel(chain(d_su, su), g[2]) <= 2e-5 and masked_rel(chain(d_sl, sl), g[3]) <= 2e-5
+
+
+def test_mix2_llama13b_shape_vs_oracle():
+    x = synth.weight(5120, 13824, 9)
+    bits = synth.mix2_bits(5120, 10)
+    up, low = synth.lwc_factors(5120, 11)
+    r = O.uniform_row(x, bits.unsqueeze(-1), False, up, low, None, clamp_asym_scale=True)
+    su, sl = sig(up, low)
+    out, scale, rzp, codes = F.rowquant_uniform_fwd(x.to(DEV), 0, False, su, sl, 0, bits.to(DEV), True, want_codes=True,
+                                                    preactivated=True)
+    assert same(out.cpu(), r.out) and same(scale.cpu(), r.scale) and same(rzp.cpu(), r.rzp)
+    assert torch.equal(codes.cpu().float(), r.codes)
+    # rows never use more levels than their bit-width allows
+    assert bool((codes.cpu().float().amax(1) <= 2 ** bits - 1).all())
+
+
+def test_row_sharded_weight_quantization_equals_full():
+    """Output-channel shards (the multi-GPU layout) need no exchange: quantizing shards == quantizing the matrix."""
+    x = synth.weight(4096, 4096, 12).to(DEV)
+    up, low = (t.to(DEV) for t in synth.lwc_factors(4096, 13))
+    full, s_full, z_full, _ = F.rowquant_uniform_fwd(x, 4, False, up, low)
+    parts = []
+    for r in range(8):
+        a, b = r * 512, (r + 1) * 512
+        o, s, z, _ = F.rowquant_uniform_fwd(x[a:b].contiguous(), 4, False, up[a:b].contiguous(), low[a:b].contiguous())
+        parts.append(o)
+    assert torch.equal(torch.cat(parts), full)
