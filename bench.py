@@ -127,8 +127,7 @@ class Workload:
             saved.clear()
             for i, (_n, shape, _dt, _c) in enumerate(SITES):
                 x2 = self.x[i].reshape(-1, shape[-1])
-                st = F.act_calibrate(x2, A_BITS, "ema_minmax", self.layout[i])
-                F.colquant_fwd(x2, st["scale"], st["rzp"], A_BITS)
+                _out, _codes, st = F.act_calib_quant_fwd(x2, A_BITS, "ema_minmax", self.layout[i])
                 saved.append(st)
 
         def a_bwd():

@@ -126,6 +126,21 @@ int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, con
                      void* dx, int64_t R, int64_t C, int n_bits, int phase, int dtype, void* stream);
 
 /*
+ * The calibrating static quantizer in one call: the whole of UniformAffineQuantizer.forward in
+ * calibration mode (quantize/quantizer.py:124-142 -> :157-238 -> :99-121).  Exactly
+ *   miq_colstat_minmax -> miq_cluster_scale (idx = NULL) -> miq_colquant_fwd
+ * with nchunk = miq_colstat_chunks(R, C, dtype); arguments as documented there.
+ * workspace: miq_act_workspace(R, C, dtype) floats = two planes of [nchunk + 1, C]; on return row
+ * nchunk of plane 0 / plane 1 holds the per-channel min / max before the cluster merge (the chan_min /
+ * chan_max inputs of miq_colquant_bwd).
+ */
+int64_t miq_act_workspace(int64_t R, int64_t C, int dtype);
+int miq_act_calib_quant_fwd(const void* x, const void* cached_min, const void* cached_max, int metric,
+                            const int* starts, int n_clusters, int64_t covered, int n_bits, float* workspace,
+                            void* out, void* codes_out, void* cmin_out, void* cmax_out, void* scale_out,
+                            void* zp_out, void* rzp_out, int64_t R, int64_t C, int dtype, void* stream);
+
+/*
  * RPTQ channel reorder: out[r, c] = x[r, idx[c]] (torch.index_select on the last axis, as in
  * OmniLayerNorm.forward, quantize/omni_norm.py:36-40).  Rows are staged through LDS so that both
  * the global loads and the global stores stay coalesced.  idx: int32 [C], entries in [0, C).

@@ -179,22 +179,6 @@ __global__ void __launch_bounds__(256) k_cluster_scale(ScaleArgs<T> a) {
     }
 }
 
-// Level of one element for a per-channel scale that is known to be finite and positive (the
-// calibrated scale is clamped to [1e-5, 1e4]; a NaN scale propagates through either path).
-template <typename T>
-__device__ __forceinline__ float col_div(float x, float s, float rs);
-template <> __device__ __forceinline__ float col_div<float>(float x, float s, float) { return x / s; }
-template <> __device__ __forceinline__ float col_div<__half>(float x, float s, float rs) {
-    const float q0 = x * rs;
-    const float e = __builtin_fmaf(-q0, s, x);   // exact residual: see Divisor<__half>
-    return __half2float(__float2half(__builtin_fmaf(e, rs, q0)));
-}
-template <typename T>
-__device__ __forceinline__ float col_level(float x, float s, float rs, float z, bool exact_int) {
-    const float xi = rint_ste(col_div<T>(x, s, rs)) + z;
-    return exact_int ? xi : rnd<T>(xi);
-}
-
 // ---------------------------------------------------------------------------------------------
 // quantize-dequantize with per-channel parameters
 // ---------------------------------------------------------------------------------------------
@@ -350,10 +334,10 @@ static int launch_gather(const void* x, const int* idx, void* out, long long R, 
     const size_t lds = (size_t)rows * row_bytes;
     const unsigned grid = (unsigned)((R + rows - 1) / rows);
     if (vec_ok) {
-        if (lds > 65536) hipFuncSetAttribute((const void*)k_gather<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_gather<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_gather<T, N>), dim3(grid), dim3(256), lds, stream, (const T*)x, idx, (T*)out, R, (int)C, rows);
     } else {
-        if (lds > 65536) hipFuncSetAttribute((const void*)k_gather<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_gather<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_gather<T, 1>), dim3(grid), dim3(256), lds, stream, (const T*)x, idx, (T*)out, R, (int)C, rows);
     }
     MIQ_CHECK_LAUNCH("miq_gather_lastdim");
@@ -429,6 +413,28 @@ extern "C" int miq_colquant_fwd(const void* x, const void* scale, const void* rz
     if (dtype == MIQ_F16) return launch_colquant_fwd<__half>(x, scale, rzp, out, codes_out, R, C, n_bits, (hipStream_t)stream);
     miq_set_error("miq_colquant_fwd: unsupported dtype %d", dtype);
     return -22;
+}
+
+extern "C" int64_t miq_act_workspace(int64_t R, int64_t C, int dtype) {
+    if (R <= 0 || C <= 0) return 0;
+    return 2ll * (miq_colstat_chunks(R, C, dtype) + 1) * C;
+}
+
+extern "C" int miq_act_calib_quant_fwd(const void* x, const void* cached_min, const void* cached_max, int metric,
+                                       const int* starts, int n_clusters, int64_t covered, int n_bits, float* workspace,
+                                       void* out, void* codes_out, void* cmin_out, void* cmax_out, void* scale_out,
+                                       void* zp_out, void* rzp_out, int64_t R, int64_t C, int dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(workspace, "miq_act_calib_quant_fwd: null workspace");
+    const int nchunk = miq_colstat_chunks(R, C, dtype);
+    float* pmin = workspace;
+    float* pmax = workspace + (int64_t)(nchunk + 1) * C;
+    int rc = miq_colstat_minmax(x, R, C, pmin, pmax, nchunk, dtype, stream);
+    if (rc) return rc;
+    rc = miq_cluster_scale(pmin, pmax, nchunk, C, nullptr, cached_min, cached_max, metric, starts, n_clusters, covered, n_bits,
+                           cmin_out, cmax_out, scale_out, zp_out, rzp_out, dtype, stream);
+    if (rc) return rc;
+    return miq_colquant_fwd(x, scale_out, rzp_out, out, codes_out, R, C, n_bits, dtype, stream);
 }
 
 extern "C" int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int64_t C, int dtype, void* stream) {

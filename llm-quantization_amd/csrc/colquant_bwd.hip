@@ -15,24 +15,6 @@
 
 namespace miq {
 
-template <typename T> __device__ __forceinline__ float cdiv(float x, float s, float rs);
-template <> __device__ __forceinline__ float cdiv<float>(float x, float s, float) { return x / s; }
-template <> __device__ __forceinline__ float cdiv<__half>(float x, float s, float rs) {
-    // exact IEEE quotient of two fp16 values from one Newton correction (see Divisor<__half>); the
-    // calibrated scale is clamped to [1e-5, 1e4], so it is never 0 or inf
-    const float q0 = x * rs;
-    const float e = __builtin_fmaf(-q0, s, x);
-    return __half2float(__float2half(__builtin_fmaf(e, rs, q0)));
-}
-
-template <typename T>
-__device__ __forceinline__ void fq_terms(float xv, float s, float rs, float z, float qmax, float& q, bool& m, float& xd) {
-    q = cdiv<T>(xv, s, rs);
-    const float xi = rnd<T>(rint_ste(q) + z);
-    m = (xi >= 0.f) && (xi <= qmax);
-    xd = rnd<T>(clampf(xi, 0.f, qmax) - z);
-}
-
 // partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)

@@ -23,7 +23,15 @@ constexpr float kClipHi = 1e4f;
 // ---------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float rnd(float v);
 template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
-template <> __device__ __forceinline__ float rnd<__half>(float v) { return __half2float(__float2half(v)); }
+// PyTorch rounds the fp32 result of an op to fp16 (two roundings).  The empty asm keeps the fp32 value
+// in a register: otherwise the compiler folds "multiply/add, then convert" into v_fma_mixlo_f16, which
+// rounds the exact result ONCE; that differs at fp16 midpoints whenever an operand is not itself an
+// fp16 value (e.g. x * 0.99f gives 35.59375 instead of 35.5625 for x = 35.9375).
+__device__ __forceinline__ __half f2h_twice_rounded(float v) {
+    asm("" : "+v"(v));
+    return __float2half(v);
+}
+template <> __device__ __forceinline__ float rnd<__half>(float v) { return __half2float(f2h_twice_rounded(v)); }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
@@ -31,7 +39,7 @@ template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __h
 
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
-template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
+template <> __device__ __forceinline__ __half from_f<__half>(float v) { return f2h_twice_rounded(v); }
 
 // widest vector (16 bytes) per dtype
 template <typename T> struct VecOf;
@@ -124,6 +132,32 @@ template <typename T> __device__ __forceinline__ bool ints_exact(float zp, float
 template <> __device__ __forceinline__ bool ints_exact<float>(float, float) { return true; }
 template <> __device__ __forceinline__ bool ints_exact<__half>(float zp, float qmax) {
     return (fabsf(zp) + qmax <= 2048.f) && (qmax < 2048.f);
+}
+
+// Level of one element for a per-channel scale that is known to be finite and positive (the
+// calibrated scale is clamped to [1e-5, 1e4]; a NaN scale propagates through either path).
+template <typename T>
+__device__ __forceinline__ float col_div(float x, float s, float rs);
+template <> __device__ __forceinline__ float col_div<float>(float x, float s, float) { return x / s; }
+template <> __device__ __forceinline__ float col_div<__half>(float x, float s, float rs) {
+    const float q0 = x * rs;
+    const float e = __builtin_fmaf(-q0, s, x);   // exact residual: see Divisor<__half>
+    return __half2float(__float2half(__builtin_fmaf(e, rs, q0)));
+}
+template <typename T>
+__device__ __forceinline__ float col_level(float x, float s, float rs, float z, bool exact_int) {
+    const float xi = rint_ste(col_div<T>(x, s, rs)) + z;
+    return exact_int ? xi : rnd<T>(xi);
+}
+
+// Terms of the static quantizer's backward for one element: q = x/s, m = "level inside [0, qmax]",
+// xd = clamp(level) - z.
+template <typename T>
+__device__ __forceinline__ void fq_terms(float xv, float s, float rs, float z, float qmax, float& q, bool& m, float& xd) {
+    q = col_div<T>(xv, s, rs);
+    const float xi = rnd<T>(rint_ste(q) + z);
+    m = (xi >= 0.f) && (xi <= qmax);
+    xd = rnd<T>(clampf(xi, 0.f, qmax) - z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -347,6 +381,7 @@ static inline bool make_geom(long long O, long long I, long long group, RowGeom&
 
 // error reporting shared by all translation units (defined in capi.hip)
 extern "C" void miq_set_error(const char* fmt, ...);
+extern "C" int miq_colstat_chunks(int64_t R, int64_t C, int dtype);
 
 #define MIQ_CHECK_ARG(cond, ...)                 \
     do {                                         \

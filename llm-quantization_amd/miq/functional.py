@@ -193,6 +193,28 @@ def colquant_fwd(x2d, scale, rzp, n_bits: int, want_codes: bool = False):
     return out, codes
 
 
+def act_calib_quant_fwd(x2d, n_bits: int, metric: str, layout: ClusterLayout, cached_min=None, cached_max=None,
+                        want_codes: bool = False):
+    """Statistics + cluster merge + scale + quantize-dequantize of an [R, C] slab through one library
+    call (miq_act_calib_quant_fwd).  Returns (out, codes|None, stats) with act_calibrate's stats dict."""
+    dev = L.check_gpu(x2d, cached_min, cached_max)
+    R, C = x2d.shape
+    code = L.dtype_code(x2d)
+    rows = colstat_chunks(R, C, x2d.dtype) + 1
+    ws = torch.empty((2, rows, C), dtype=torch.float32, device=dev)
+    outs = torch.empty((5, C), dtype=x2d.dtype, device=dev)
+    out = torch.empty_like(x2d)
+    codes = torch.empty((R, C), dtype=torch.uint8, device=dev) if want_codes else None
+    with torch.cuda.device(dev):
+        L.call("miq_act_calib_quant_fwd", L.ptr(x2d), L.ptr(cached_min), L.ptr(cached_max),
+               L.i32(1 if metric == "ema_minmax" else 0), L.ptr(layout.starts), L.i32(layout.n_clusters),
+               L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(ws), L.ptr(out), L.ptr(codes), L.ptr(outs[0]), L.ptr(outs[1]),
+               L.ptr(outs[2]), L.ptr(outs[3]), L.ptr(outs[4]), L.i64(R), L.i64(C), L.i32(code), L.stream_of(x2d))
+    stats = {"cmin": outs[0], "cmax": outs[1], "scale": outs[2], "zp": outs[3], "rzp": outs[4],
+             "chan_min": ws[0, rows - 1], "chan_max": ws[1, rows - 1]}
+    return out, codes, stats
+
+
 def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
     """route = (chan_min, chan_max, kmin, kmax, layout) enables the min/max routing (calibration mode).
     With a stats-synchronised DPContext the per-channel sums are all-reduced between the two phases."""
@@ -277,9 +299,12 @@ class ActCalibFQ(torch.autograd.Function):
     def forward(ctx, x, n_bits, metric, layout, cached_min, cached_max, holder, dp=None):
         x = x.contiguous()
         x2 = x.reshape(-1, x.shape[-1])
-        st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max, dp=dp)
         ctx.dp = dp
-        out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
+        if dp is not None and dp.active and dp.sync_stats:
+            st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max, dp=dp)
+            out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
+        else:
+            out, _, st = act_calib_quant_fwd(x2, n_bits, metric, layout, cached_min, cached_max)
         holder.update(st)
         ctx.fresh = cached_min is None
         ctx.layout = layout
