@@ -266,3 +266,165 @@ class QuantOPTBlock(_BlockBase):
 
     # names of the linears that receive a LET scale/shift pair, and the reorder index each pair follows
     LET_PAIRS = {"q_proj": ("qkv", "R1"), "out_proj": ("out", "R3"), "fc1": ("fc1", "R4")}
+
+
+# ------------------------------------------------------------------------------------------------
+# Llama
+# ------------------------------------------------------------------------------------------------
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class _Rotary(nn.Module):
+    """Rotary position embedding in the Hugging Face Llama layout (the two halves of a head are the
+    real / imaginary parts).  cos/sin tables are built once per (length, device, dtype)."""
+
+    def __init__(self, head_dim: int, theta: float = 10000.0):
+        super().__init__()
+        self.head_dim, self.theta = head_dim, theta
+        self._tab = None
+
+    def tables(self, position_ids, device, dtype):
+        key = (position_ids.data_ptr(), position_ids._version, tuple(position_ids.shape), str(device), dtype)
+        if self._tab is None or self._tab[0] != key:
+            inv = 1.0 / (self.theta ** (torch.arange(0, self.head_dim, 2, dtype=torch.float32, device=device) / self.head_dim))
+            freqs = position_ids.to(device=device, dtype=torch.float32)[..., None] * inv  # [b, t, hd/2]
+            emb = torch.cat((freqs, freqs), dim=-1)
+            self._tab = (key, emb.cos().to(dtype).unsqueeze(1), emb.sin().to(dtype).unsqueeze(1))  # [b, 1, t, hd]
+        return self._tab[1], self._tab[2]
+
+    def forward(self, q, k, position_ids):
+        cos, sin = self.tables(position_ids, q.device, q.dtype)
+        return q * cos + _rotate_half(q) * sin, k * cos + _rotate_half(k) * sin
+
+
+class _LlamaAttention(nn.Module):
+    """reference models/int_llama_layer.py:48-179 (no KV cache: calibration always sees whole sequences)."""
+
+    def __init__(self, q, k, v, o, num_heads, num_kv_heads, args, rope_theta=10000.0, nbits=None):
+        super().__init__()
+        self.hidden_size = q.weight.shape[1]
+        self.num_heads = num_heads
+        self.head_dim = self.hidden_size // num_heads
+        self.num_key_value_heads = num_kv_heads
+        self.num_key_value_groups = num_heads // num_kv_heads
+        if self.head_dim * num_heads != self.hidden_size:
+            raise ValueError(f"hidden_size {self.hidden_size} must be divisible by num_heads {num_heads}")
+        self.rotary_emb = _Rotary(self.head_dim, rope_theta)
+        kw = dict(weight_exp_quant=args.weight_exp_quant, weight_mix_quant=args.weight_mix_quant,
+                  weight_mix2_quant=args.weight_mix2_quant)
+        nb = nbits or {}
+        self.k_proj = QuantLinear(k, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("k", []), **kw)
+        self.v_proj = QuantLinear(v, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("v", []), **kw)
+        self.q_proj = QuantLinear(q, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("q", []), **kw)
+        self.o_proj = QuantLinear(o, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("o", []), **kw)
+        self.qkt_matmul = QuantMatMul(args.q_quant_params, args.k_quant_params, matmul_func=torch.matmul)
+        self.pv_matmul = QuantMatMul(args.p_quant_params, args.v_quant_params, matmul_func=torch.matmul)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None):
+        bsz, q_len, _ = hidden_states.size()
+        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim).transpose(1, 2)
+        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        if position_ids is None:
+            position_ids = torch.arange(q_len, device=hidden_states.device).unsqueeze(0)
+        q, k = self.rotary_emb(q, k, position_ids)
+        if self.num_key_value_groups > 1:
+            k = k[:, :, None].expand(bsz, self.num_key_value_heads, self.num_key_value_groups, q_len, self.head_dim)
+            k = k.reshape(bsz, self.num_heads, q_len, self.head_dim)
+            v = v[:, :, None].expand(bsz, self.num_key_value_heads, self.num_key_value_groups, q_len, self.head_dim)
+            v = v.reshape(bsz, self.num_heads, q_len, self.head_dim)
+        q = self.qkt_matmul.quant_x1(q)
+        k = self.qkt_matmul.quant_x2(k)
+        w = self.qkt_matmul(q, k.transpose(2, 3)) / (self.head_dim ** 0.5)
+        if attention_mask is not None:
+            w = w + attention_mask
+            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+        w = TF.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+        w = self.pv_matmul.quant_x1(w)
+        v = self.pv_matmul.quant_x2(v)
+        o = self.pv_matmul(w, v)
+        o = o.transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
+        return self.o_proj(o)
+
+
+class _LlamaMLP(nn.Module):
+    def __init__(self, gate, up, down, args, nbits=None):
+        super().__init__()
+        kw = dict(weight_exp_quant=args.weight_exp_quant, weight_mix_quant=args.weight_mix_quant,
+                  weight_mix2_quant=args.weight_mix2_quant)
+        nb = nbits or {}
+        self.gate_proj = QuantLinear(gate, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("gate", []), **kw)
+        self.down_proj = QuantLinear(down, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("down", []), **kw)
+        self.up_proj = QuantLinear(up, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("up", []), **kw)
+
+    def forward(self, x):
+        return self.down_proj(TF.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class QuantLlamaBlock(_BlockBase):
+    """Llama decoder block (RMSNorm -> attention with rotary embedding and grouped KV heads ->
+    residual; RMSNorm -> SwiGLU MLP -> residual), the layout of the reference's
+    QuantLlamaDecoderLayer (models/int_llama_layer.py:191-368).
+
+    ``weights``: dict with 2-D tensors q, k, v, o, gate, up, down (optional biases ``<name>_b``) and
+    the norm weights ln1_w, ln2_w.
+    """
+
+    LET_PAIRS = {"q_proj": ("qkv", "R1"), "o_proj": ("out", "R3"), "up_proj": ("fc1", "R4")}
+
+    def __init__(self, weights: dict, num_heads: int, args, num_kv_heads=None, nbits=None, eps=1e-6, rope_theta=10000.0):
+        super().__init__()
+        w = weights
+        self.hidden_size = w["q"].shape[1]
+        self.self_attn = _LlamaAttention(_linear(w["q"], w.get("q_b")), _linear(w["k"], w.get("k_b")),
+                                         _linear(w["v"], w.get("v_b")), _linear(w["o"], w.get("o_b")), num_heads,
+                                         num_kv_heads or num_heads, args, rope_theta, nbits)
+        self.mlp = _LlamaMLP(_linear(w["gate"], w.get("gate_b")), _linear(w["up"], w.get("up_b")),
+                             _linear(w["down"], w.get("down_b")), args, nbits)
+        n1, n2 = SimpleNamespace(weight=w["ln1_w"].detach().clone()), SimpleNamespace(weight=w["ln2_w"].detach().clone())
+        self.input_layernorm = OmniLlamaRMSNorm(n1, eps=eps)
+        self.post_attention_layernorm = OmniLlamaRMSNorm(n2, eps=eps)
+        self.let = bool(getattr(args, "let", False))
+        self.num_heads = num_heads
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, **_kw):
+        residual = hidden_states
+        h = self.input_layernorm(hidden_states)
+        h = self.self_attn(h, attention_mask=attention_mask, position_ids=position_ids)
+        h = residual + h
+        residual = h
+        h = self.mlp(self.post_attention_layernorm(h))
+        return (residual + h,)
+
+    def smooth_and_quant_temporary(self):
+        a, m = self.self_attn, self.mlp
+        if self.let:
+            self._truncate_scales()
+            smooth_ln_fcs_temporary(self.input_layernorm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
+                                    self.qkv_smooth_shift)
+            smooth_ln_fcs_temporary(self.post_attention_layernorm, [m.up_proj, m.gate_proj], self.fc1_smooth_scale,
+                                    self.fc1_smooth_shift)
+            smooth_fc_fc_temporary(a.v_proj, a.o_proj, self.out_smooth_scale, self.out_smooth_shift)
+            smooth_q_k_temporary(a.q_proj, a.k_proj, self.qkt_smooth_scale)
+            m.down_proj.temp_weight = m.down_proj.weight
+        else:
+            for _n, mod in self.quant_linears():
+                mod.temp_weight = mod.weight
+        self._quantize_temp_weights()
+
+    @torch.no_grad()
+    def smooth_and_quant_inplace(self):
+        a, m = self.self_attn, self.mlp
+        if self.let:
+            self._truncate_scales()
+            smooth_ln_fcs_inplace(self.input_layernorm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
+                                  self.qkv_smooth_shift)
+            smooth_ln_fcs_inplace(self.post_attention_layernorm, [m.up_proj, m.gate_proj], self.fc1_smooth_scale,
+                                  self.fc1_smooth_shift)
+            smooth_fc_fc_inplace(a.v_proj, a.o_proj, self.out_smooth_scale, self.out_smooth_shift)
+            smooth_q_k_inplace(a.q_proj, a.k_proj, self.qkt_smooth_scale)
+        for _n, mod in self.quant_linears():
+            mod.weight = mod.weight_quantizer(mod.weight)
+            mod.use_temporary_parameter = False

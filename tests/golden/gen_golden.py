@@ -537,6 +537,7 @@ def main():
     fams = {"uniform": gen_uniform, "mix2": gen_mix2, "exp1": gen_exp1, "exp2": gen_exp2, "mix": gen_mix,
             "act": gen_act, "reorder": gen_reorder}
     fams["block"] = lambda _ref: gen_block(args.ref)
+    fams["block_llama"] = lambda _ref: gen_block_llama(args.ref)
     for fam, fn in fams.items():
         if args.only and fam not in args.only.split(","):
             continue
@@ -723,6 +724,154 @@ def gen_block(ref_root):
     RU.oc_maxmin_dict.clear()
     RU.ic_maxmin_dict.clear()
     return {"opt_tiny_w4a4_reorder": d}
+
+
+# ---------------------------------------------------------------------------------------------
+# Llama block fixture: the reference's QuantLlamaDecoderLayer (models/int_llama_layer.py) driven by
+# the llama branch of omniquant() (pairs q_proj/o_proj/up_proj, zero shifts, no reorder, static
+# per-tensor EMA activation quantizers = the reference's CLI defaults), fp32 path.
+# Harness shims for the installed transformers: the source layer carries its own rotary object with
+# the old call convention (value_states, seq_len=) -> (cos, sin) of shape [1, T, head_dim], and
+# position_ids is the integer 1, which today's apply_rotary_pos_emb takes as its unsqueeze_dim.
+# ---------------------------------------------------------------------------------------------
+def gen_block_llama(ref_root):
+    import types as _t
+    import warnings
+
+    for name in ("auto_gptq", "auto_gptq.nn_modules", "auto_gptq.nn_modules.qlinear", "auto_gptq.nn_modules.qlinear.qlinear_cuda"):
+        sys.modules.setdefault(name, _t.ModuleType(name))
+    from models.int_llama_layer import QuantLlamaDecoderLayer
+    from quantize.int_linear import QuantLinear
+    from quantize.int_matmul import QuantMatMul
+    import utils as ref_utils
+
+    H, Fd, heads, T, N, epochs = 64, 160, 4, 32, 4, 2
+    hd = H // heads
+    wbits, abits, theta, eps = 4, 4, 10000.0, 1e-5
+    g = synth.gen(191)
+
+    def lin(i, o):
+        l = torch.nn.Linear(i, o, bias=False)
+        with torch.no_grad():
+            l.weight.copy_(torch.randn(o, i, generator=g) * 0.08)
+        return l
+
+    class Rotary(torch.nn.Module):
+        def forward(self, x, seq_len=None):
+            inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+            freqs = torch.arange(seq_len, dtype=torch.float32)[:, None] * inv
+            emb = torch.cat((freqs, freqs), dim=-1)
+            return emb.cos()[None].to(x.dtype), emb.sin()[None].to(x.dtype)
+
+    def norm(c):
+        n = torch.nn.Module()
+        n.weight = torch.nn.Parameter(torch.rand(c, generator=g) + 0.5)
+        n.variance_epsilon = eps
+        return n
+
+    src = torch.nn.Module()
+    src.self_attn = torch.nn.Module()
+    a = src.self_attn
+    a.q_proj, a.k_proj, a.v_proj, a.o_proj = lin(H, H), lin(H, H), lin(H, H), lin(H, H)
+    a.rotary_emb = Rotary()
+    src.mlp = torch.nn.Module()
+    src.mlp.gate_proj, src.mlp.up_proj, src.mlp.down_proj = lin(H, Fd), lin(H, Fd), lin(Fd, H)
+    src.input_layernorm, src.post_attention_layernorm = norm(H), norm(H)
+    src = src.half()
+
+    act = {"n_bits": abits, "per_channel_axes": [], "symmetric": False, "dynamic_method": "per_tensor", "dynamic": False,
+           "metric": "ema_minmax"}
+    args = _t.SimpleNamespace(
+        weight_quant_params={"n_bits": wbits, "per_channel_axes": [0], "symmetric": False, "dynamic_method": "per_channel",
+                             "group_size": None, "lwc": True, "dynamic": True, "metric": "minmax", "target_bit": wbits},
+        act_quant_params=dict(act), q_quant_params=dict(act), k_quant_params=dict(act), v_quant_params=dict(act),
+        p_quant_params={"n_bits": 16, "metric": "fix0to1"},
+        let=True, alpha=0.5, let_lr=5e-3, lwc_lr=1e-2, wd=0.0, batch_size=1, nsamples=N, epochs=epochs)
+    config = _t.SimpleNamespace(hidden_size=H, num_attention_heads=heads, num_key_value_heads=heads,
+                                max_position_embeddings=T, intermediate_size=Fd, hidden_act="silu")
+    qlayer = QuantLlamaDecoderLayer(config, src, args)
+    d = {"meta": {"H": H, "F": Fd, "heads": heads, "T": T, "N": N, "epochs": epochs, "wbits": wbits, "abits": abits,
+                  "theta": theta, "eps": eps}}
+    for n, m in (("q", a.q_proj), ("k", a.k_proj), ("v", a.v_proj), ("o", a.o_proj), ("gate", src.mlp.gate_proj),
+                 ("up", src.mlp.up_proj), ("down", src.mlp.down_proj)):
+        d[f"w_{n}"] = m.weight.detach().float().clone()
+    d["w_ln1_w"] = src.input_layernorm.weight.detach().float().clone()
+    d["w_ln2_w"] = src.post_attention_layernorm.weight.detach().float().clone()
+
+    inps = synth.activation((N, T, H), 192) * 0.5
+    d["inps"] = inps.clone()
+    mask = torch.full((T, T), torch.finfo(torch.float32).min).triu(1).view(1, 1, T, T)
+    d["mask"] = mask.clone()
+    position_ids = 1  # see the header comment
+    prefix = "model.layers.0"
+    act_scales = {}
+    for name in ("self_attn.q_proj", "self_attn.o_proj", "mlp.up_proj"):
+        act_scales[f"{prefix}.{name}"] = torch.rand(H, generator=g) * 3 + 0.2
+        d[f"act_scale_{name}"] = act_scales[f"{prefix}.{name}"]
+
+    quant_inps, fp_inps = inps.clone(), inps.clone()
+    qlayer.set_quant_state(weight_quant=False, act_quant=False)
+    with torch.no_grad():
+        qlayer.float()  # CPU stand-in for the CUDA autocast of omniquant.py:402, as in the OPT fixture
+        for j in range(N):
+            fp_inps[j] = qlayer(fp_inps[j].unsqueeze(0), attention_mask=mask, position_ids=position_ids)[0]
+    d["fp_out"] = fp_inps.clone()
+    qlayer.set_quant_state(weight_quant=False, act_quant=True)
+    qlayer.let = True
+    dtype = torch.float32
+    pairs = {"q_proj": "qkv", "o_proj": "out", "up_proj": "fc1"}
+    qlayer.register_parameter("qkt_smooth_scale", torch.nn.Parameter(torch.ones(H, dtype=dtype)))
+    for name, module in qlayer.named_modules():
+        if isinstance(module, QuantLinear):
+            for key in pairs:
+                if key in name:
+                    actv = act_scales[f"{prefix}.{name}"].clamp(min=1e-5)
+                    weight = module.weight.max(dim=0)[0].clamp(min=1e-5)
+                    scale = (actv.pow(args.alpha) / weight.pow(1 - args.alpha)).clamp(min=1e-5)
+                    shift = torch.zeros_like(scale)  # omniquant.py:434-444: no shift statistics for llama
+                    qlayer.register_parameter(f"{pairs[key]}_smooth_shift", torch.nn.Parameter(shift))
+                    qlayer.register_parameter(f"{pairs[key]}_smooth_scale", torch.nn.Parameter(scale))
+    with torch.no_grad():
+        qlayer.float()
+    optimizer = torch.optim.AdamW([{"params": qlayer.let_parameters(True), "lr": args.let_lr},
+                                   {"params": qlayer.lwc_parameters(), "lr": args.lwc_lr}], weight_decay=args.wd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss_scaler = ref_utils.NativeScalerWithGradNormCount()
+    loss_func = torch.nn.MSELoss()
+    losses, norms = [], []
+    for _epoch in range(epochs):
+        for j in range(N):
+            qlayer.smooth_and_quant_temporary()
+            out = qlayer(quant_inps[j:j + 1], attention_mask=mask, position_ids=position_ids)[0]
+            loss = loss_func(fp_inps[j:j + 1], out)
+            optimizer.zero_grad()
+            norm_ = loss_scaler(loss, optimizer, parameters=qlayer.omni_parameters(True))
+            losses.append(loss.detach().clone())
+            norms.append(norm_.detach().clone())
+            for _n, m in qlayer.named_modules():
+                if isinstance(m, QuantLinear) and not m.disable_input_quant:
+                    m.act_quantizer.free()
+                if isinstance(m, QuantMatMul):
+                    m.x1_quantizer.free()
+                    m.x2_quantizer.free()
+    qlayer.clear_temp_variable()
+    d["losses"], d["norms"] = torch.stack(losses), torch.stack(norms)
+    for k, v in qlayer.omni_state_dict().items():
+        d[f"omni_fp32_{k}"] = v.detach().clone()
+    qlayer.smooth_and_quant_inplace()
+    with torch.no_grad():
+        for j in range(N):
+            quant_inps[j] = qlayer(quant_inps[j].unsqueeze(0), attention_mask=mask, position_ids=position_ids)[0]
+    d["quant_out"] = quant_inps.clone()
+    for name, m in qlayer.named_modules():
+        if isinstance(m, QuantLinear) and not m.disable_input_quant:
+            d[f"actscale_{name}"] = m.act_quantizer.scale.detach().clone()
+            d[f"actrzp_{name}"] = m.act_quantizer.round_zero_point.detach().clone()
+        if isinstance(m, QuantLinear):
+            d[f"wq_{name}"] = m.weight.detach().clone()
+    d["omni_keys"] = list(qlayer.omni_state_dict().keys())
+    return {"llama_tiny_w4a4_pertensor": d}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,78 @@
+"""Llama block calibration on the GPU against a fixture captured from the reference's own
+QuantLlamaDecoderLayer + the llama branch of omniquant() (tests/golden/block_llama.pt): tiny
+Llama-shaped block (hidden 64, SwiGLU 160, 4 heads, rotary, RMSNorm, 32 tokens, 4 samples, 2 epochs),
+W4A4 with the reference's default static per-tensor EMA activation quantizers, LET (zero shifts) +
+LWC, fp32 path.
+
+Tolerances as for the OPT block: the quantizer kernels are bit-exact, the GEMMs / softmax / norms
+around them run on another device than the fixture, and 8 optimizer steps amplify that rounding."""
+import pytest
+import torch
+
+from helpers import golden, rel_err
+from miq.blocks import QuantLlamaBlock, quant_args
+from miq.calibrate import CalibConfig, calibrate_layer, finalize_layer, init_let
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PREFIX = "model.layers.0"
+LET_SITES = ("self_attn.q_proj", "self_attn.o_proj", "mlp.up_proj")
+
+
+def build(d):
+    m = d["meta"]
+    w = {n: d[f"w_{n}"].to(DEV) for n in ("q", "k", "v", "o", "gate", "up", "down", "ln1_w", "ln2_w")}
+    args = quant_args(wbits=m["wbits"], abits=m["abits"], lwc=True, a_dynamic_method="per_tensor", metric="ema_minmax", let=True)
+    return QuantLlamaBlock(w, m["heads"], args, eps=m["eps"], rope_theta=m["theta"]).to(DEV)
+
+
+def config(m):
+    return CalibConfig(epochs=m["epochs"], nsamples=m["N"], batch_size=1, let=True, lwc=True, deactive_amp=True, reorder="")
+
+
+def test_tiny_llama_block_matches_reference_run():
+    d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+    m = d["meta"]
+    q = build(d)
+    act_scales = {f"{PREFIX}.{n}": d[f"act_scale_{n}"] for n in LET_SITES}
+    quant_inps = d["inps"].clone().to(DEV)
+    fp_inps = d["inps"].clone().to(DEV)
+    res = calibrate_layer(q, quant_inps, fp_inps, d["mask"].to(DEV), config(m), act_scales, {}, PREFIX, is_llama=True)
+    assert rel_err(fp_inps, d["fp_out"]) <= 1e-5
+    losses, norms = torch.tensor(res["losses"]), torch.tensor(res["norms"])
+    assert torch.allclose(losses, d["losses"], rtol=2e-2), (losses, d["losses"])
+    assert torch.allclose(norms, d["norms"], rtol=5e-2), (norms, d["norms"])
+    state = res["omni_state"]
+    assert list(state.keys()) == d["omni_keys"]
+    for k in d["omni_keys"]:
+        ref, got = d[f"omni_fp32_{k}"], state[k].float().cpu()
+        assert got.shape == ref.shape, k
+        assert (got - ref).abs().max().item() <= 2e-3 + 1e-3 * ref.abs().max().item(), k
+    qo = quant_inps.cpu()
+    assert ((qo - d["quant_out"]).abs().mean() / d["quant_out"].abs().mean()).item() <= 5e-2
+
+
+def test_llama_propagation_with_reference_parameters():
+    """The reference's learned parameters loaded, then only the tail of the layer procedure: quantized
+    weights, accumulated per-tensor activation scales and propagated activations must agree closely."""
+    d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+    m = d["meta"]
+    q = build(d)
+    cfg = config(m)
+    act_scales = {f"{PREFIX}.{n}": d[f"act_scale_{n}"] for n in LET_SITES}
+    q.set_quant_state(weight_quant=False, act_quant=True)
+    q.let = True
+    init_let(q, act_scales, {}, PREFIX, cfg, None, torch.float32, torch.device(DEV), is_llama=True)
+    state = {k: d[f"omni_fp32_{k}"].to(DEV) for k in d["omni_keys"]}
+    _missing, unexpected = q.load_state_dict(state, strict=False)
+    assert not unexpected
+    quant_inps = d["inps"].clone().to(DEV)
+    finalize_layer(q, quant_inps, d["mask"].to(DEV), cfg)
+    for name, mod in q.named_modules():
+        if f"wq_{name}" in d:
+            w, r = mod.weight.float().cpu(), d[f"wq_{name}"]
+            assert ((w - r.half().float()).abs() > 1e-6).float().mean().item() <= 2e-3, name
+        if f"actscale_{name}" in d:
+            assert rel_err(mod.act_quantizer.scale.float().cpu().reshape(-1), d[f"actscale_{name}"].reshape(-1)) <= 2e-3, name
+    qo = quant_inps.cpu()
+    assert ((qo - d["quant_out"]).abs().mean() / d["quant_out"].abs().mean()).item() <= 2e-3
