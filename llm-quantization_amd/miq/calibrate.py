@@ -17,6 +17,7 @@ owner keeps the result.
 from __future__ import annotations
 
 import math
+import time
 import os
 from contextlib import nullcontext
 from dataclasses import dataclass, field
@@ -233,6 +234,12 @@ def _set_dp(qlayer, dp):
         q.dp = dp if (dp is not None and dp.active and dp.sync_stats) else None
 
 
+def _now(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    return time.perf_counter()
+
+
 def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfig, act_scales=None, act_shifts=None,
                     layer_prefix: str = "model.decoder.layers.0", dims=None, dp: Optional[DPContext] = None,
                     position_ids=None, logger=None, reorder_stats_layer=None, indices=None, is_llama=False):
@@ -248,6 +255,14 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
     n_local = quant_inps.shape[0]
     n_total = cfg.nsamples
     use_amp = not cfg.deactive_amp
+    seconds: Dict[str, float] = {}
+    clock = [_now(dev)]
+
+    def lap(name):
+        t = _now(dev)
+        seconds[name] = seconds.get(name, 0.0) + t - clock[0]
+        clock[0] = t
+
     dtype = torch.float32 if (cfg.deactive_amp and cfg.epochs > 0) else torch.float16
     traincast = (lambda: torch.autocast("cuda", dtype=torch.float16)) if use_amp else nullcontext
     loss_func = nn.MSELoss()
@@ -277,6 +292,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
         hidden, ffn, heads = dims
         indices = reorder_block(qlayer, hidden, ffn, heads, enable, cfg.n_clusters, dev)
 
+    lap("reorder")
     # ---- full-precision targets -------------------------------------------------------------
     qlayer.set_quant_state(weight_quant=False, act_quant=False)
     if cfg.epochs > 0:
@@ -287,6 +303,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
             for j in range(n_local):
                 fp_inps[j] = qlayer(fp_inps[j].unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]
 
+    lap("fp_targets")
     qlayer.set_quant_state(weight_quant=False, act_quant=True)  # weights are quantized by hand before each forward
     qlayer.let = cfg.let
     if cfg.let:
@@ -335,9 +352,12 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                 logger.info(f"{layer_prefix} epoch {epoch} loss:{np.mean(losses[-k:])} norm:{np.mean(norms[-k:])}")
         qlayer.clear_temp_variable()
         del optimizer
+    lap("train")
 
     finalize_layer(qlayer, quant_inps, attention_mask, cfg, dp, position_ids)
-    return {"losses": losses, "norms": norms, "indices": indices, "omni_state": qlayer.omni_state_dict()}
+    lap("propagate")
+    return {"losses": losses, "norms": norms, "indices": indices, "omni_state": qlayer.omni_state_dict(),
+            "seconds": seconds}
 
 
 def finalize_layer(qlayer, quant_inps, attention_mask, cfg: CalibConfig, dp: Optional[DPContext] = None, position_ids=None):
