@@ -224,12 +224,41 @@ def cpu_baseline(threads: int):
                       f"fwd+bwd on [1,2048,4096] fp32), torch CPU oracle, {dt:.1f} s"}
 
 
+def block_calib(dev, world, rank):
+    """Second half of the metric: seconds per layer of the block-calibration loop (GEMMs and attention
+    are PyTorch-ROCm, the quantizer ops are the kernels benchmarked above).  Outside the timed region
+    of `value`.  One rank: the reference's own published configuration (its committed OPT-125m run
+    log) and a Llama-2-7B block in the fp32 and fp16-autocast paths; N ranks: the Llama-2-7B block with
+    the samples sharded over the ranks and the per-step gradient all-reduce."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import bench_block as BB
+    from miq.dist import DPContext
+
+    out = {}
+    try:
+        if world == 1:
+            out["reference_log_opt125m_w3exp_a8"] = BB.run(dev=dev, **BB.REFERENCE_LOG)
+            out["llama2_7b_w4a4_fp32"] = BB.run("7b", 8, 2, False, "per_tensor", dev=dev)
+            out["llama2_7b_w4a4_amp"] = BB.run("7b", 8, 2, True, "per_tensor", dev=dev)
+        else:
+            dp = DPContext.from_env()
+            out["llama2_7b_w4a4_fp32"] = BB.run("7b", 4, 2, False, "per_tensor", dev=dev, dp=dp)
+            out["llama2_7b_w4a4_amp"] = BB.run("7b", 4, 2, True, "per_tensor", dev=dev, dp=dp)
+    except Exception as e:  # the headline line must survive a failure of this auxiliary measurement
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-block-calib", action="store_true")
+    ap.add_argument("--block-calib", action="store_true",
+                    help="with N > 1 ranks: also time the data-parallel block calibration (off by default there: a rank "
+                         "that fails inside it would leave the others waiting in a collective before the result line)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
     args = ap.parse_args()
 
@@ -277,16 +306,24 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    totals_local = seg.totals_ms()
+    by_local = wl.bytes()
+    launches = wl.launches()
+    del wl, fams
+    torch.cuda.empty_cache()
+    want_blk = (world == 1 and not args.no_block_calib) or (world > 1 and args.block_calib and not rehearsal)
+    blk = block_calib(dev, world, rank) if want_blk else None
+
     if rank == 0:
-        by = wl.bytes()
+        by = by_local
         step_bytes = sum(by.values())
-        totals = seg.totals_ms()
+        totals = totals_local
         fam = {k: {"GBps": round(by[k] * args.steps / (totals[k] * 1e-3) / 1e9, 1),
                    "frac_hbm_peak": round(by[k] * args.steps / (totals[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                   "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": wl.launches()[k]}
+                   "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": launches[k]}
                for k in by}
         dom = max(totals, key=totals.get)
-        n_launch = wl.launches()[dom] * args.steps
+        n_launch = launches[dom] * args.steps
         achieved = by[dom] * args.steps / (totals[dom] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
@@ -315,10 +352,12 @@ def main():
             "frac_hbm_peak": round(step_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": by[dom] // wl.launches()[dom],
+                         "bytes_per_launch": by[dom] // launches[dom],
                          "avg_launch_us": round(totals[dom] * 1e3 / n_launch, 2)},
             "families": fam,
         }
+        if blk is not None:
+            out["block_calib"] = blk
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
         print(json.dumps(out))
