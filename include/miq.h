@@ -196,6 +196,13 @@ int miq_rowquant_mix_bwd(const void* grad_out, const void* x, const void* up, co
 int miq_reorder_index(const float* xmax, const float* xmin, int64_t C, int n_heads, int64_t* index_out,
                       void* stream);
 
+/*
+ * Sensitivity statistic behind the per-output-channel bit allocation (get_grads.py:201-205):
+ * acc[o] += mean over i of |g[o, i]| for a row-major [O, I] weight gradient; acc is fp32 [O] and is
+ * accumulated over calls (the caller zeroes it once per layer).
+ */
+int miq_row_absmean_accum(const void* g, float* acc, int64_t O, int64_t I, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

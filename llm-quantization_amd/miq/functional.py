@@ -182,6 +182,29 @@ def act_calibrate(x2d, n_bits: int, metric: str, layout: ClusterLayout, cached_m
             "chan_min": part[0, fold], "chan_max": part[1, fold]}
 
 
+def channel_minmax(x2d):
+    """Per-channel (min, max) over the rows of an [R, C] slab, fp32 [C] each (one streaming pass)."""
+    dev = L.check_gpu(x2d)
+    R, C = x2d.shape
+    nchunk = colstat_chunks(R, C, x2d.dtype)
+    part = torch.empty((2, nchunk, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.call("miq_colstat_minmax", L.ptr(x2d), L.i64(R), L.i64(C), L.ptr(part[0]), L.ptr(part[1]), L.i32(nchunk),
+               L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
+    return part[0].amin(0), part[1].amax(0)
+
+
+def row_absmean_accum(g2d, acc):
+    """acc[o] += mean_i |g[o, i]| (fp32 accumulator of O entries, updated in place)."""
+    dev = L.check_gpu(g2d, acc)
+    O, I = g2d.shape
+    if acc.dtype != torch.float32 or acc.numel() != O or not acc.is_contiguous():
+        raise L.MiqError("accumulator must be a contiguous float32 vector with one entry per row")
+    with torch.cuda.device(dev):
+        L.call("miq_row_absmean_accum", L.ptr(g2d), L.ptr(acc), L.i64(O), L.i64(I), L.i32(L.dtype_code(g2d)), L.stream_of(g2d))
+    return acc
+
+
 def colquant_fwd(x2d, scale, rzp, n_bits: int, want_codes: bool = False):
     dev = L.check_gpu(x2d, scale, rzp)
     R, C = x2d.shape

@@ -380,3 +380,39 @@ def reorder_index(xmax, xmin, n_clusters: int, n_heads: Optional[int] = None, st
 
 def gather_lastdim(x, index):
     return torch.index_select(x, x.ndim - 1, index)
+
+
+# --------------------------------------------------------------------------------------------
+# activation scale / shift statistics and sensitivity-driven bit allocation
+# --------------------------------------------------------------------------------------------
+def act_scale_update(prev: Optional[torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """Running per-channel abs-max of a Linear input (generate_act_scale_shift.py:31-38)."""
+    t = x.reshape(-1, x.shape[-1]).abs().detach()
+    coming = torch.max(t, dim=0)[0].float().cpu()
+    return coming if prev is None else torch.max(prev, coming)
+
+
+def act_shift_update(prev: Optional[torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """0.99/0.01 EMA of the per-channel (max+min)/2 of a Linear input (generate_act_scale_shift.py:64-72)."""
+    t = x.reshape(-1, x.shape[-1]).detach()
+    mx = torch.max(t, dim=0)[0].float().cpu()
+    mn = torch.min(t, dim=0)[0].float().cpu()
+    mid = (mx + mn) / 2
+    return mid if prev is None else 0.99 * prev + 0.01 * mid
+
+
+def row_absmean(g: torch.Tensor) -> torch.Tensor:
+    """Per-output-channel sensitivity term of one sample (get_grads.py:204)."""
+    return torch.mean(torch.abs(g), dim=1)
+
+
+def allocate_bits(sensitivity: torch.Tensor) -> torch.Tensor:
+    """10 % most sensitive channels 4 bits, 10 % least sensitive 2 bits, the rest 3 (get_grads.py:222-230).
+    Parity unpinned: the reference holds this inside a script body that cannot be imported."""
+    _v, indices = torch.sort(sensitivity, descending=True)
+    n = sensitivity.shape[0]
+    bits = torch.zeros_like(sensitivity)
+    bits[indices[0:int(n * 0.1)]] = 4
+    bits[indices[int(n * 0.1):int(n * 0.9)]] = 3
+    bits[indices[int(n * 0.9):]] = 2
+    return bits

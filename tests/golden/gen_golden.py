@@ -538,6 +538,7 @@ def main():
             "act": gen_act, "reorder": gen_reorder}
     fams["block"] = lambda _ref: gen_block(args.ref)
     fams["block_llama"] = lambda _ref: gen_block_llama(args.ref)
+    fams["act_stats"] = lambda _ref: gen_act_stats(args.ref)
     for fam, fn in fams.items():
         if args.only and fam not in args.only.split(","):
             continue
@@ -872,6 +873,28 @@ def gen_block_llama(ref_root):
             d[f"wq_{name}"] = m.weight.detach().clone()
     d["omni_keys"] = list(qlayer.omni_state_dict().keys())
     return {"llama_tiny_w4a4_pertensor": d}
+
+
+# ---------------------------------------------------------------------------------------------
+# act scale / shift generator: the reference's get_act_scales / get_act_shifts
+# (generate_act_scale_shift.py:26-95) on a toy model whose Linear inputs are exact elementwise
+# functions of the sample (so that they are the same bits on any device).
+# ---------------------------------------------------------------------------------------------
+def gen_act_stats(ref_root):
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import StatToy
+    import generate_act_scale_shift as G
+    import tqdm as _tqdm
+    G.tqdm = lambda it: it  # silence the progress bar
+    cases = {}
+    for name, dt, n, shape in (("f32", torch.float32, 5, (1, 33, 96)), ("f16", torch.float16, 4, (2, 17, 96))):
+        model = StatToy().to(dt)
+        samples = [(synth.activation(shape, 700 + i, dt),) for i in range(n)]
+        scales = G.get_act_scales(model, samples, n)
+        shifts = G.get_act_shifts(model, samples, n)
+        cases[name] = {"meta": {"dtype": name, "n": n, "shape": list(shape), "seed0": 700},
+                       "scales": scales, "shifts": shifts}
+    return cases
 
 
 if __name__ == "__main__":

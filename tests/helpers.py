@@ -77,3 +77,21 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     a, b = torch.nan_to_num(a, nan=0.0, posinf=0.0, neginf=0.0), torch.nan_to_num(b, nan=0.0, posinf=0.0, neginf=0.0)
     den = b.abs().max().item()
     return (a - b).abs().max().item() / (den if den > 0 else 1.0)
+
+
+class StatToy(torch.nn.Module):
+    """Toy model for the activation-statistics fixtures: every nn.Linear input is an exact elementwise
+    function of the sample, so the hooked tensors are the same bits on every device."""
+    def __init__(self, c=96, k=40, seed=7):
+        super().__init__()
+        g = synth.gen(seed)
+        self.a = torch.nn.Linear(c, 8)
+        self.b = torch.nn.Linear(c, 8)
+        self.c = torch.nn.Linear(k, 8, bias=False)
+        self.k = k
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+
+    def forward(self, x):
+        return self.a(x).sum() + self.b(torch.relu(x) * 0.5 + 1.0).sum() + self.c(-x[..., :self.k]).sum()

@@ -145,3 +145,31 @@ def test_reference_shipped_checkpoint_loads_into_block():
     assert all(("smooth" not in m and "bound_factor" not in m) for m in missing)
     assert torch.equal(blk.fc1.weight_quantizer.upbound_factor.detach().half(), ck[3]["fc1.weight_quantizer.upbound_factor"])
     assert set(blk.omni_state_dict().keys()) == set(ck[3].keys())
+
+
+def test_reference_act_scale_shift_files_feed_let_init():
+    """The act_scales / act_shifts files the reference ships for OPT-125m (73 entries keyed by module
+    name, float32 [in_features]) are consumed as they are by the LET initialisation."""
+    import os
+    from miq.blocks import QuantOPTBlock, quant_args
+    from miq.calibrate import CalibConfig, init_let
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    scales = torch.load(os.path.join(here, "ref_act_scales_opt125m.pt"), weights_only=True)
+    shifts = torch.load(os.path.join(here, "ref_act_shifts_opt125m.pt"), weights_only=True)
+    assert len(scales) == len(shifts) == 73 and set(scales) == set(shifts)
+    H, Fd = 768, 3072
+    assert scales["model.decoder.layers.0.fc2"].shape == (Fd,) and scales["model.decoder.layers.11.fc1"].dtype == torch.float32
+    g = torch.Generator().manual_seed(0)
+    w = {}
+    for n, (o, i) in {"q": (H, H), "k": (H, H), "v": (H, H), "o": (H, H), "fc1": (Fd, H), "fc2": (H, Fd)}.items():
+        w[n] = torch.randn(o, i, generator=g) * 0.02
+        w[f"{n}_b"] = torch.zeros(o)
+    for n in ("ln1", "ln2"):
+        w[f"{n}_w"], w[f"{n}_b"] = torch.ones(H), torch.zeros(H)
+    q = QuantOPTBlock(w, 12, quant_args(let=True))
+    init_let(q, scales, shifts, "model.decoder.layers.3", CalibConfig(), None, torch.float32, torch.device("cpu"))
+    names = {n for n, _p in q.named_parameters() if "smooth" in n}
+    assert names == {"qkt_smooth_scale", "qkv_smooth_scale", "qkv_smooth_shift", "out_smooth_scale", "out_smooth_shift",
+                     "fc1_smooth_scale", "fc1_smooth_shift"}
+    assert torch.equal(q.fc1_smooth_shift.detach(), shifts["model.decoder.layers.3.fc1"])
+    assert bool((q.qkv_smooth_scale > 0).all()) and bool(torch.isfinite(q.out_smooth_scale).all())

@@ -181,3 +181,29 @@ def test_gather_matches_wiring_fixture():
     g = O.gather_lastdim(x3, d["ln1_reorder_index"])
     ref = torch.nn.functional.layer_norm(g, (x3.shape[-1],), d["post_ln1_w"], d["post_ln1_b"], 1e-5)
     assert same(ref, d["ln1_out3"])
+
+
+# --------------------------------------------------------------------------------------------
+# activation scale / shift statistics (fixture produced by the reference's get_act_scales /
+# get_act_shifts) and the bit allocation rule
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["f32", "f16"])
+def test_act_stats_oracle_matches_reference_functions(name):
+    from helpers import StatToy
+    d = golden("act_stats")[name]
+    m = d["meta"]
+    dt = DT[m["dtype"]]
+    k = StatToy().k
+    scales, shifts = {}, {}
+    for i in range(m["n"]):
+        x = synth.activation(tuple(m["shape"]), m["seed0"] + i, dt)
+        for key, inp in (("a", x), ("b", torch.relu(x) * 0.5 + 1.0), ("c", -x[..., :k])):
+            scales[key] = O.act_scale_update(scales.get(key), inp)
+            shifts[key] = O.act_shift_update(shifts.get(key), inp)
+    for key in ("a", "b", "c"):
+        assert same(scales[key], d["scales"][key]) and same(shifts[key], d["shifts"][key]), key
+
+
+def test_allocate_bits_rule():
+    s = torch.tensor([0.5, 0.1, 0.9, 0.3, 0.7, 0.2, 0.8, 0.4, 0.6, 0.05])
+    assert O.allocate_bits(s).tolist() == [3, 3, 4, 3, 3, 3, 3, 3, 3, 2]
