@@ -136,6 +136,25 @@ class _BlockBase(nn.Module):
                 m.temp_bias = m.bias
             m.use_temporary_parameter = True
 
+    fused_let = True  # use the LET-fused weight quantizer kernels when the configuration allows
+
+    def _let_fusable(self):
+        from .quantizer import UniformAffineQuantizer
+        return self.fused_let and all(type(m.weight_quantizer) is UniformAffineQuantizer and m.weight_quantizer.let_fusable(m.weight)
+                                      for _n, m in self.quant_linears())
+
+    @staticmethod
+    def _let_linear(m, cs=None, rs=None, rs_div=True, shift=None):
+        """temp_weight / temp_bias of one linear: quantize((W * cs) / rs or * rs); bias + W @ shift.
+        The caller applies the row factor and the output shift to the bias (small vectors)."""
+        wq, wshift = m.weight_quantizer.forward_let(m.weight, cs, rs, rs_div, shift)
+        m.temp_weight = wq
+        if wshift is None:
+            m.temp_bias = m.bias
+        else:
+            m.temp_bias = m.bias + wshift if m.bias is not None else wshift
+        m.use_temporary_parameter = True
+
     def _truncate_scales(self):
         with torch.no_grad():
             for n, p in self.named_parameters():
@@ -235,8 +254,32 @@ class QuantOPTBlock(_BlockBase):
         h = self.fc2(TF.relu(self.fc1(h)))
         return ((residual + h).view(shape),)
 
+    def _fused_let_temporary(self):
+        """smooth_*_temporary + weight quantization (reference int_opt_layer.py:404-444) with the
+        smoothed weights formed inside the quantizer kernels; biases follow models/transformation.py:24-69."""
+        a = self.self_attn
+        s1, b1, so, bo, sq = (self.qkv_smooth_scale, self.qkv_smooth_shift, self.out_smooth_scale, self.out_smooth_shift,
+                              self.qkt_smooth_scale)
+        for ln, sc, sh in ((self.self_attn_layer_norm, s1, b1), (self.final_layer_norm, self.fc1_smooth_scale, self.fc1_smooth_shift)):
+            ln.use_temporary_parameter = True
+            ln.temp_bias = (ln.bias - sh) / sc if getattr(ln, "bias", None) is not None else (-1 * sh) / sc
+            ln.temp_weight = ln.weight / sc
+        self._let_linear(a.q_proj, s1, sq, True, b1)
+        a.q_proj.temp_bias = a.q_proj.temp_bias / sq.view(-1)
+        self._let_linear(a.k_proj, s1, sq, False, b1)
+        a.k_proj.temp_bias = a.k_proj.temp_bias * sq.view(-1)
+        self._let_linear(a.v_proj, s1, so, True, b1)
+        a.v_proj.temp_bias = (a.v_proj.temp_bias - bo) / so.view(-1)
+        self._let_linear(a.out_proj, so, None, True, bo)
+        self._let_linear(self.fc1, self.fc1_smooth_scale, None, True, self.fc1_smooth_shift)
+        self._let_linear(self.fc2)
+
     def smooth_and_quant_temporary(self):
         a = self.self_attn
+        if self.let and self._let_fusable():
+            self._truncate_scales()
+            self._fused_let_temporary()
+            return
         if self.let:
             self._truncate_scales()
             smooth_ln_fcs_temporary(self.self_attn_layer_norm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
@@ -398,8 +441,34 @@ class QuantLlamaBlock(_BlockBase):
         h = self.mlp(self.post_attention_layernorm(h))
         return (residual + h,)
 
+    def _fused_let_temporary(self):
+        """smooth_*_temporary + weight quantization (reference int_llama_layer.py:279-307) with the
+        smoothed weights formed inside the quantizer kernels."""
+        a, m = self.self_attn, self.mlp
+        s1, b1, so, bo, sq = (self.qkv_smooth_scale, self.qkv_smooth_shift, self.out_smooth_scale, self.out_smooth_shift,
+                              self.qkt_smooth_scale)
+        sf, bf = self.fc1_smooth_scale, self.fc1_smooth_shift
+        for ln, sc, sh in ((self.input_layernorm, s1, b1), (self.post_attention_layernorm, sf, bf)):
+            ln.use_temporary_parameter = True
+            ln.temp_bias = (ln.bias - sh) / sc if getattr(ln, "bias", None) is not None else (-1 * sh) / sc
+            ln.temp_weight = ln.weight / sc
+        self._let_linear(a.q_proj, s1, sq, True, b1)
+        a.q_proj.temp_bias = a.q_proj.temp_bias / sq.view(-1)
+        self._let_linear(a.k_proj, s1, sq, False, b1)
+        a.k_proj.temp_bias = a.k_proj.temp_bias * sq.view(-1)
+        self._let_linear(a.v_proj, s1, so, True, b1)
+        a.v_proj.temp_bias = (a.v_proj.temp_bias - bo) / so.view(-1)
+        self._let_linear(a.o_proj, so, None, True, bo)
+        self._let_linear(m.up_proj, sf, None, True, bf)
+        self._let_linear(m.gate_proj, sf, None, True, bf)
+        self._let_linear(m.down_proj)
+
     def smooth_and_quant_temporary(self):
         a, m = self.self_attn, self.mlp
+        if self.let and self._let_fusable():
+            self._truncate_scales()
+            self._fused_let_temporary()
+            return
         if self.let:
             self._truncate_scales()
             smooth_ln_fcs_temporary(self.input_layernorm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,

@@ -146,6 +146,21 @@ class UniformAffineQuantizer(nn.Module):
         with torch.no_grad():
             self._row_dynamic(x)
 
+    def let_fusable(self, w) -> bool:
+        """True when forward_let() may replace `forward((w * cs) / rs)` for this quantizer and weight."""
+        return (self.enable and self.n_bits < 16 and self.metric != "fix0to1" and self.dynamic
+                and self.dynamic_method in ("per_token", "per_channel") and F.let_supported(w, self.group_size or 0))
+
+    def forward_let(self, w, cs=None, rs=None, rs_div=True, shift=None):
+        """Quantize the smoothed weight (w * cs[None, :]) / rs[:, None] (``rs_div``) or * rs[:, None]
+        without materialising it, and return it with w @ shift (None without ``shift``).  Same result
+        as forward() on the materialised tensor; gradients reach cs, rs, shift and the LWC factors."""
+        up, low = self._lwc_params(w)
+        out, wshift, scale, rzp = F.LetRowFQ.apply(w, cs, rs, bool(rs_div), shift, up, low, self.n_bits, bool(self.symmetric))
+        self.scale = scale
+        self.round_zero_point = rzp
+        return out, (wshift if shift is not None else None)
+
     # ------------------------------------------------------------------ static activations
     def _layout(self, x):
         C = x.shape[-1]

@@ -76,3 +76,55 @@ def test_llama_propagation_with_reference_parameters():
             assert rel_err(mod.act_quantizer.scale.float().cpu().reshape(-1), d[f"actscale_{name}"].reshape(-1)) <= 2e-3, name
     qo = quant_inps.cpu()
     assert ((qo - d["quant_out"]).abs().mean() / d["quant_out"].abs().mean()).item() <= 2e-3
+
+
+@pytest.mark.parametrize("kind", ["llama", "opt"])
+def test_fused_let_step_equals_unfused_step(kind):
+    """One training step with the LET-fused weight-quantizer kernels against the same step through the
+    reference's op chain (smooth_*_temporary, then the stand-alone quantizer kernels): the quantized
+    weights are bit-identical, the loss agrees to fp32 rounding of the bias terms, and every LET / LWC
+    gradient agrees to 1e-4 of its norm."""
+    from miq.int_linear import QuantLinear
+    if kind == "llama":
+        d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+        builder, prefix, sites, is_llama = build, PREFIX, LET_SITES, True
+        shifts = {}
+    else:
+        import test_gpu_block_calibration as opt
+        d = golden("block")["opt_tiny_w4a4_reorder"]
+        builder, prefix, is_llama = opt.build, "model.decoder.layers.0", False
+        sites = ("self_attn.q_proj", "self_attn.out_proj", "fc1")
+        shifts = {f"{prefix}.{n}": d[f"act_shift_{n}"] for n in sites}
+    m = d["meta"]
+    cfg = config(m)
+    act_scales = {f"{prefix}.{n}": d[f"act_scale_{n}"] for n in sites}
+    x = d["inps"][:1].to(DEV)
+    mask = d["mask"].to(DEV)
+    results = []
+    for fused in (True, False):
+        q = builder(d)
+        q.fused_let = fused
+        q.set_quant_state(weight_quant=False, act_quant=True)
+        q.let = True
+        init_let(q, act_scales, shifts, prefix, cfg, None, torch.float32, torch.device(DEV), is_llama=is_llama)
+        with torch.no_grad():
+            q.float()
+            for n, p in q.named_parameters():  # move the parameters off their initial values
+                if "smooth_shift" in n:
+                    p.add_(0.05 * torch.sin(torch.arange(p.numel(), device=DEV, dtype=torch.float32)))
+                if "qkt_smooth_scale" in n:
+                    p.mul_(1.0 + 0.1 * torch.cos(torch.arange(p.numel(), device=DEV, dtype=torch.float32)))
+        assert q._let_fusable() == fused
+        q.smooth_and_quant_temporary()
+        out = q(x, attention_mask=mask)[0]
+        loss = (out ** 2).mean()
+        names = [n for n, _p in q.named_parameters() if "smooth" in n or "bound_factor" in n]
+        grads = torch.autograd.grad(loss, [dict(q.named_parameters())[n] for n in names])
+        wq = {n: mod.temp_weight.detach().clone() for n, mod in q.named_modules() if isinstance(mod, QuantLinear)}
+        results.append((float(loss.detach()), dict(zip(names, grads)), wq))
+    (l1, g1, w1), (l0, g0, w0) = results
+    for n in w0:
+        assert torch.equal(w1[n], w0[n]), n
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    for n in g0:
+        assert rel_err(g1[n].cpu(), g0[n].cpu()) <= 1e-4, (n, rel_err(g1[n].cpu(), g0[n].cpu()))
