@@ -197,29 +197,31 @@ int miq_reorder_index(const float* xmax, const float* xmin, int64_t C, int n_hea
                       void* stream);
 
 /*
- * LET-fused row-wise uniform weight quantizer (fp32, whole rows, I % 4 == 0, I <= 16384).
+ * LET-fused row-wise uniform weight quantizer (fp32 weights, whole rows, I % 4 == 0, I <= 16384).
  * Forward: out = fake_quant_rows(t) with t = (w * cs[None,:]) / rs[:,None]  (rs_div = 1) or
  * (w * cs[None,:]) * rs[:,None] (rs_div = 0), the smoothed weight that smooth_ln_fcs_temporary /
  * smooth_fc_fc_temporary / smooth_q_k_temporary (models/transformation.py:24-69) materialise
  * before UniformAffineQuantizer.forward (quantize/quantizer.py:124-142); same IEEE operations in the
  * same order, so `out`, `scale_out`, `rzp_out` are bit-identical to that chain (for pre-activated
  * clipping factors; see MIQ_LWC_PREACTIVATED).  cs, rs, shift, up/low may each be NULL.
+ * out_dtype MIQ_F16 stores the fp32 result rounded to fp16 (what the autocast of the consuming
+ * linear would produce from the fp32 tensor).
  * With `shift`, wshift_out[o] = sum_i w[o,i] * shift[i] (the `fc.weight @ shifts` term of the
  * smoothed bias; fp32 accumulation in kernel order).
- * Backward: given grad_out = dL/d out and g_wshift = dL/d wshift, returns d_cs [I], d_rs [O],
- * d_shift [I], d_up / d_low [O] (each optional: pass NULL to skip) — what autograd derives through
- * the same chain.  workspace: miq_let_partial_rows(O, I) * I floats for each of d_cs and d_shift
- * that is requested.
+ * Backward: given grad_out = dL/d out (fp32 or fp16, grad_dtype) and g_wshift = dL/d wshift, returns
+ * d_cs [I], d_rs [O], d_shift [I], d_up / d_low [O] (each optional: pass NULL to skip) — what
+ * autograd derives through the same chain.  workspace: miq_let_workspace(O, I) floats, needed when
+ * d_cs or d_shift is requested.
  */
-int miq_let_partial_rows(int64_t O, int64_t I);
+int64_t miq_let_workspace(int64_t O, int64_t I);
 int miq_let_rowquant_fwd(const float* w, const float* cs, const float* rs, int rs_div, const float* shift,
-                         const float* up, const float* low, float* out, float* scale_out, float* rzp_out,
+                         const float* up, const float* low, void* out, float* scale_out, float* rzp_out,
                          float* wshift_out, int64_t O, int64_t I, int n_bits, int symmetric, int flags,
-                         void* stream);
-int miq_let_rowquant_bwd(const float* grad_out, const float* g_wshift, const float* w, const float* cs,
+                         int out_dtype, void* stream);
+int miq_let_rowquant_bwd(const void* grad_out, const float* g_wshift, const float* w, const float* cs,
                          const float* rs, int rs_div, const float* shift, const float* up, const float* low,
                          float* d_cs, float* d_rs, float* d_shift, float* d_up, float* d_low, float* workspace,
-                         int64_t O, int64_t I, int n_bits, int symmetric, int flags, void* stream);
+                         int64_t O, int64_t I, int n_bits, int symmetric, int flags, int grad_dtype, void* stream);
 
 /*
  * Sensitivity statistic behind the per-output-channel bit allocation (get_grads.py:201-205):

@@ -88,33 +88,41 @@ __device__ __forceinline__ float let_apply(float w, float cs, bool has_cs, float
     return t;
 }
 
-template <int TEAM, int NV>
+template <typename TO, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
-k_let_fwd(LetArgs a, float* __restrict__ out, float* __restrict__ scale_out, float* __restrict__ rzp_out,
+k_let_fwd(LetArgs a, TO* __restrict__ out, float* __restrict__ scale_out, float* __restrict__ rzp_out,
           float* __restrict__ wshift_out) {
     __shared__ float lds[48];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
     const int npack = a.I / 4;
     const bool has_cs = a.cs != nullptr, has_r = a.rs != nullptr, rdiv = a.rs_div != 0;
-    ColVec<TEAM, NV> cs, sh;
-    cs.load(a.cs, npack, lane);
-    if (a.shift) sh.load(a.shift, npack, lane);
+    (void)npack;
+    // one row per team per iteration; the column vectors (a few KB, L2-resident) are read at use
     for (long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM; row < a.O; row += (long long)gridDim.x * RPB) {
         RowTile<float, 4, TEAM, NV> x;
         x.load(a.w + row * a.I, a.I, lane);
-        if (a.shift) {
-            float d[1] = {0.f};
-            x.for_each([&](int k, int e, float w) { d[0] += w * sh.at(k, e); });
-            team_sum<TEAM, 1>(d, lds);
-            if (lane == 0) wshift_out[row] = d[0];
-        }
         const float r = has_r ? a.rs[row] : 1.f;
+        float d[1] = {0.f};
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
+            if (a.shift) {
+                const float4 s4 = *reinterpret_cast<const float4*>(a.shift + x.offset(k));
+                d[0] += x.v[k].e[0] * s4.x;
+                d[0] += x.v[k].e[1] * s4.y;
+                d[0] += x.v[k].e[2] * s4.z;
+                d[0] += x.v[k].e[3] * s4.w;
+            }
+            float4 c4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (has_cs) c4 = *reinterpret_cast<const float4*>(a.cs + x.offset(k));
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x.v[k].e[e] = let_apply(x.v[k].e[e], cs.at(k, e), has_cs, r, has_r, rdiv);
+            for (int e = 0; e < 4; ++e) x.v[k].e[e] = let_apply(x.v[k].e[e], cv[e], has_cs, r, has_r, rdiv);
+        }
+        if (a.shift) {
+            team_sum<TEAM, 1>(d, lds);
+            if (lane == 0) wshift_out[row] = d[0];
         }
         float rmin, rmax;
         row_minmax(x, false, lds, rmin, rmax);
@@ -126,136 +134,183 @@ k_let_fwd(LetArgs a, float* __restrict__ out, float* __restrict__ scale_out, flo
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
-            Pack<float, 4> o;
+            Pack<TO, 4> o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xi = rint_ste(x.v[k].e[e] / c.s) + c.rzp;
-                o.e[e] = (clampf(xi, 0.f, c.qmax) - c.rzp) * c.s;
+                // TO = __half: the fp32 result rounded once more, i.e. what a cast of the fp32 tensor gives
+                o.e[e] = from_f<TO>((clampf(xi, 0.f, c.qmax) - c.rzp) * c.s);
             }
-            st_pack<float, 4>(out + row * a.I + x.offset(k), o);
+            st_pack<TO, 4>(out + row * a.I + x.offset(k), o);
         }
     }
 }
 
-// Backward.  dt = gradient w.r.t. t through the quantizer (straight-through pass + the routing of the
-// scale gradient to the row extremes, as in k_uniform_bwd).  Then
-//   d_rs[o]    = sum_i -dt * (t / r)     (division)      |  sum_i dt * (w*cs)   (multiplication)
-//   d_t1       = dt / r                                  |  dt * r
-//   d_cs[i]    = sum_o d_t1 * w
-//   d_shift[i] = sum_o w * g_wshift[o]
-template <int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_let_bwd(LetArgs a, const float* __restrict__ gout, const float* __restrict__ g_wshift, float* __restrict__ d_up,
-          float* __restrict__ d_low, float* __restrict__ d_rs, float* __restrict__ part_cs, float* __restrict__ part_sh) {
+// Backward in two streaming launches (both read w and the incoming gradient once; the second read is
+// served from the Infinity Cache for matrices below ~100 MiB):
+//   rows kernel   one row per team (like k_uniform_bwd): row statistics, dS, tie counts -> d_up, d_low,
+//                 d_rs, and the per-row context {s, rzp, rmax, rmin, share_max, share_min} for the
+//                 column kernel;
+//   cols kernel   lane = 4 columns, wave = every 4th row of a row chunk: rebuilds
+//                 dt = [level inside the grid] * g + shares at the row extremes, and accumulates
+//                 d_cs[i] = sum_o d_t1 * w and d_shift[i] = sum_o w * g_wshift[o] per chunk; a small
+//                 fold sums the chunks (deterministic).
+// With dt the gradient w.r.t. t:
+//   d_rs[o] = sum_i -dt * (t / r)   (division)   |   sum_i dt * (w*cs)   (multiplication)
+//   d_t1    = dt / r                             |   dt * r
+// A register-resident single pass (rows strided over persistent teams, column sums in registers) was
+// measured at 1.2 TB/s: three dependent team reductions per row with only two rows in flight per CU.
+struct RowCtx {
+    float s, rzp, rmax, rmin, share_max, share_min, pad0, pad1;
+};
+
+template <typename TG, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>(), 4)
+k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up, float* __restrict__ d_low,
+               float* __restrict__ d_rs, RowCtx* __restrict__ rowctx) {
     __shared__ float lds[64];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
-    const int team = threadIdx.x / TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= a.O) return;
     const int npack = a.I / 4;
     const bool has_cs = a.cs != nullptr, has_r = a.rs != nullptr, rdiv = a.rs_div != 0;
-    const bool want_cs = part_cs != nullptr, want_sh = part_sh != nullptr;
-    ColVec<TEAM, NV> cs, acc_cs, acc_sh;
-    cs.load(a.cs, npack, lane);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) acc_cs.v[k] = acc_sh.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long row = (long long)blockIdx.x * RPB + team; row < a.O; row += (long long)gridDim.x * RPB) {
-        RowTile<float, 4, TEAM, NV> w, g;
-        w.load(a.w + row * a.I, a.I, lane);
-        g.load(gout + row * a.I, a.I, lane);
-        const float r = has_r ? a.rs[row] : 1.f;
-        if (want_sh) {
-            const float gs = g_wshift[row];
-            w.for_each([&](int k, int e, float wv) { acc_sh.at(k, e) += wv * gs; });
-        }
-        // statistics of the transformed row
-        float mn = __builtin_inff(), mx = -__builtin_inff();
-        w.for_each([&](int k, int e, float wv) {
-            const float t = let_apply(wv, cs.at(k, e), has_cs, r, has_r, rdiv);
-            mn = nmin(mn, t);
-            mx = nmax(mx, t);
-        });
-        float mm[2] = {mn, mx};
-        team_reduce<TEAM, 2>(mm, OpMinMax(), lds);
-        const float rmin = mm[0], rmax = mm[1];
-        const LetCtx c = let_ctx(a, row, rmin, rmax);
-        float acc[3] = {0.f, 0.f, 0.f};  // dS, #t == rmax, #t == rmin
-        unsigned long long inside = 0ull;
-        static_assert(NV * 4 <= 64, "mask of un-clamped elements is one 64-bit word");
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (!w.has(k)) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = let_apply(w.v[k].e[e], cs.at(k, e), has_cs, r, has_r, rdiv);
-                const float gv = g.v[k].e[e];
-                const float q = t / c.s;
-                const float xi = rint_ste(q) + c.rzp;
-                const bool m = (xi >= 0.f) && (xi <= c.qmax);
-                const float xd = clampf(xi, 0.f, c.qmax) - c.rzp;
-                acc[0] += gv * (xd - (m ? q : 0.f));
-                inside |= (m ? 1ull : 0ull) << (k * 4 + e);
-                acc[1] += (t == rmax) ? 1.f : 0.f;
-                acc[2] += (t == rmin) ? 1.f : 0.f;
-            }
-        }
-        team_sum<TEAM, 3>(acc, lds);
-        float d_xmax, d_xmin;
-        if (a.symmetric) {
-            const bool live = c.s_raw >= kClipLo && c.s_raw <= kClipHi;
-            ClipCtx cl;
-            cl.su = c.su; cl.sl = c.sl; cl.xmax = c.xmax; cl.xmin = c.xmin;
-            route_absmax(live ? acc[0] / c.qdiv : 0.f, cl, d_xmax, d_xmin);
-        } else {
-            d_xmax = acc[0] / c.qmax;
-            d_xmin = -d_xmax;
-        }
-        if (a.up && lane == 0) {
-            const float ju = a.preact ? 1.f : c.su * (1.f - c.su);
-            const float jl = a.preact ? 1.f : c.sl * (1.f - c.sl);
-            d_up[row] = d_xmax * rmax * ju;
-            d_low[row] = d_xmin * rmin * jl;
-        }
-        const float share_max = (d_xmax * c.su) / acc[1];
-        const float share_min = (d_xmin * c.sl) / acc[2];
-        float drow[1] = {0.f};
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (!w.has(k)) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float wv = w.v[k].e[e];
-                const float t1 = has_cs ? wv * cs.at(k, e) : wv;
-                const float t = has_r ? (rdiv ? t1 / r : t1 * r) : t1;
-                float dt = ((inside >> (k * 4 + e)) & 1ull) ? g.v[k].e[e] : 0.f;
-                if (t == rmax) dt += share_max;
-                if (t == rmin) dt += share_min;
-                float d_t1 = dt;
-                if (has_r) {
-                    if (rdiv) {
-                        drow[0] += -dt * (t / r);
-                        d_t1 = dt / r;
-                    } else {
-                        drow[0] += dt * t1;
-                        d_t1 = dt * r;
-                    }
-                }
-                if (want_cs) acc_cs.at(k, e) += d_t1 * wv;
-            }
-        }
-        if (has_r && d_rs) {
-            team_sum<TEAM, 1>(drow, lds);
-            if (lane == 0) d_rs[row] = drow[0];
-        }
-    }
-    // one partial row per team (teams that had no row write zeros)
-    const long long prow = (long long)blockIdx.x * RPB + team;
+    RowTile<float, 4, TEAM, NV> w;
+    RowTile<TG, 4, TEAM, NV> g;
+    w.load(a.w + row * a.I, a.I, lane);
+    g.load(gout + row * a.I, a.I, lane);
+    const float r = has_r ? a.rs[row] : 1.f;
+    // w.v <- t (the column factors are read once per element: the row kernel touches each once)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const int j = k * TEAM + lane;
-        if (j >= npack) continue;
-        if (want_cs) *reinterpret_cast<float4*>(part_cs + prow * a.I + (long long)j * 4) = acc_cs.v[k];
-        if (want_sh) *reinterpret_cast<float4*>(part_sh + prow * a.I + (long long)j * 4) = acc_sh.v[k];
+        if (!w.has(k)) continue;
+        float4 c4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (has_cs) c4 = *reinterpret_cast<const float4*>(a.cs + w.offset(k));
+        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w.v[k].e[e] = let_apply(w.v[k].e[e], cv[e], has_cs, r, has_r, rdiv);
     }
+    (void)npack;
+    float rmin, rmax;
+    row_minmax(w, false, lds, rmin, rmax);
+    const LetCtx c = let_ctx(a, row, rmin, rmax);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // dS, #t == rmax, #t == rmin, sum of m*g*t (straight-through part of d_rs)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!w.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = w.v[k].e[e];
+            const float gv = to_f<TG>(g.v[k].e[e]);
+            const float q = t / c.s;
+            const float xi = rint_ste(q) + c.rzp;
+            const bool m = (xi >= 0.f) && (xi <= c.qmax);
+            const float xd = clampf(xi, 0.f, c.qmax) - c.rzp;
+            acc[0] += gv * (xd - (m ? q : 0.f));
+            acc[1] += (t == rmax) ? 1.f : 0.f;
+            acc[2] += (t == rmin) ? 1.f : 0.f;
+            acc[3] += m ? gv * t : 0.f;
+        }
+    }
+    team_sum<TEAM, 4>(acc, lds);
+    float d_xmax, d_xmin;
+    if (a.symmetric) {
+        const bool live = c.s_raw >= kClipLo && c.s_raw <= kClipHi;
+        ClipCtx cl;
+        cl.su = c.su; cl.sl = c.sl; cl.xmax = c.xmax; cl.xmin = c.xmin;
+        route_absmax(live ? acc[0] / c.qdiv : 0.f, cl, d_xmax, d_xmin);
+    } else {
+        d_xmax = acc[0] / c.qmax;
+        d_xmin = -d_xmax;
+    }
+    if (lane != 0) return;
+    if (a.up) {
+        const float ju = a.preact ? 1.f : c.su * (1.f - c.su);
+        const float jl = a.preact ? 1.f : c.sl * (1.f - c.sl);
+        d_up[row] = d_xmax * rmax * ju;
+        d_low[row] = d_xmin * rmin * jl;
+    }
+    const float tot_max = d_xmax * c.su, tot_min = d_xmin * c.sl;  // gradient mass routed to the row max / min
+    if (has_r && d_rs) {
+        // sum_i dt*t with dt = m*g + shares at the extremes (t == rmax / rmin there): division by r for the
+        // quotient rule, identity for the product rule (dt * t1 with t1 = t / r up to one rounding)
+        const float sum_dt_t = acc[3] + tot_max * rmax + tot_min * rmin;
+        d_rs[row] = rdiv ? -sum_dt_t / r : sum_dt_t / r;
+    }
+    if (rowctx) {
+        RowCtx o;
+        o.s = c.s; o.rzp = c.rzp; o.rmax = rmax; o.rmin = rmin;
+        o.share_max = tot_max / acc[1];
+        o.share_min = tot_min / acc[2];
+        o.pad0 = o.pad1 = 0.f;
+        rowctx[row] = o;
+    }
+}
+
+template <typename TG>
+__global__ void __launch_bounds__(256)
+k_let_bwd_cols(LetArgs a, const TG* __restrict__ gout, const float* __restrict__ g_wshift, const RowCtx* __restrict__ rowctx,
+               int rows_per_chunk, float* __restrict__ part_cs, float* __restrict__ part_sh) {
+    __shared__ float4 sm[2][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * 4;
+    const bool valid = col0 < a.I;
+    const bool has_cs = a.cs != nullptr, has_r = a.rs != nullptr, rdiv = a.rs_div != 0;
+    const bool want_cs = part_cs != nullptr, want_sh = part_sh != nullptr;
+    const float qmax = exp2f((float)a.n_bits) - 1.0f;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > a.O) r1 = a.O;
+    float acs[4] = {0.f, 0.f, 0.f, 0.f}, ash[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        float cv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (has_cs) {
+            const float4 c4 = *reinterpret_cast<const float4*>(a.cs + col0);
+            cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
+        }
+        auto body = [&](long long row, const Pack<float, 4>& w, const Pack<TG, 4>& g) {
+            const RowCtx c = rowctx[row];  // wave-uniform address
+            const float r = has_r ? a.rs[row] : 1.f;
+            const float gs = want_sh ? g_wshift[row] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float wv_ = w.e[e];
+                const float t = let_apply(wv_, cv[e], has_cs, r, has_r, rdiv);
+                const float xi = rint_ste(t / c.s) + c.rzp;
+                float dt = ((xi >= 0.f) && (xi <= qmax)) ? to_f<TG>(g.e[e]) : 0.f;
+                if (t == c.rmax) dt += c.share_max;
+                if (t == c.rmin) dt += c.share_min;
+                const float d_t1 = has_r ? (rdiv ? dt / r : dt * r) : dt;
+                acs[e] += d_t1 * wv_;
+                ash[e] += wv_ * gs;
+            }
+        };
+        long long row = r0 + wv;
+        for (; row + 4 < r1; row += 8) {
+            const long long ra = __builtin_amdgcn_readfirstlane((int)row), rb = ra + 4;
+            const Pack<float, 4> w0 = ld_pack<float, 4>(a.w + ra * a.I + col0), w1 = ld_pack<float, 4>(a.w + rb * a.I + col0);
+            const Pack<TG, 4> g0 = ld_pack<TG, 4>(gout + ra * a.I + col0), g1 = ld_pack<TG, 4>(gout + rb * a.I + col0);
+            body(ra, w0, g0);
+            body(rb, w1, g1);
+        }
+        for (; row < r1; row += 4) {
+            const long long ra = __builtin_amdgcn_readfirstlane((int)row);
+            const Pack<float, 4> w0 = ld_pack<float, 4>(a.w + ra * a.I + col0);
+            const Pack<TG, 4> g0 = ld_pack<TG, 4>(gout + ra * a.I + col0);
+            body(ra, w0, g0);
+        }
+    }
+    sm[0][wv][lane] = make_float4(acs[0], acs[1], acs[2], acs[3]);
+    sm[1][wv][lane] = make_float4(ash[0], ash[1], ash[2], ash[3]);
+    __syncthreads();
+    if (wv != 0 || !valid) return;
+    auto fold = [&](int which) {
+        const float4 p0 = sm[which][0][lane], p1 = sm[which][1][lane], p2 = sm[which][2][lane], p3 = sm[which][3][lane];
+        return make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                           (p0.w + p1.w) + (p2.w + p3.w));
+    };
+    if (want_cs) *reinterpret_cast<float4*>(part_cs + (long long)blockIdx.y * a.I + col0) = fold(0);
+    if (want_sh) *reinterpret_cast<float4*>(part_sh + (long long)blockIdx.y * a.I + col0) = fold(1);
 }
 
 // out[c] = sum over the nrows partial rows; block = 64 columns x 4 waves (wave w takes rows w, w+4, ...)
@@ -281,27 +336,29 @@ k_colsum(const float* __restrict__ part, int nrows, int C, float* __restrict__ o
     if (w == 0 && c < C) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
-// number of blocks: enough to fill the chip, few enough that the partial rows stay a small fraction
-// of the matrix
-static inline int let_grid(long long O, int rpb) {
-    long long nb = (O + rpb - 1) / rpb;
-    const long long cap = 512;
-    return (int)(nb < cap ? nb : cap);
-}
-
-#define LET_DISPATCH(NPACK, L)                \
-    do {                                      \
-        if ((NPACK) <= 64) { L(16, 4); }      \
+#define LET_DISPATCH(NPACK, L)                   \
+    do {                                         \
+        if ((NPACK) <= 64) { L(16, 4); }         \
         else if ((NPACK) <= 256) { L(64, 4); }   \
         else if ((NPACK) <= 1024) { L(256, 4); } \
         else if ((NPACK) <= 2048) { L(256, 8); } \
-        else { L(512, 8); }                   \
+        else { L(512, 8); }                      \
     } while (0)
 
 static inline int let_rpb(int npack) {
     if (npack <= 64) return 256 / 16;
     if (npack <= 256) return 256 / 64;
     return 1;
+}
+
+// row chunks of the column kernel: ~1024 blocks, at least 16 rows per chunk
+static inline int let_chunks(long long O, long long I) {
+    const long long tiles = (I / 4 + 63) / 64;
+    long long want = 1024 / (tiles > 0 ? tiles : 1);
+    const long long maxc = (O + 15) / 16;
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    return (int)want;
 }
 
 static int let_check(const char* name, const LetArgs& a) {
@@ -313,41 +370,74 @@ static int let_check(const char* name, const LetArgs& a) {
     return 0;
 }
 
+template <typename TO>
+static void let_fwd_launch(const LetArgs& a, void* out, float* scale_out, float* rzp_out, float* wshift_out, hipStream_t stream) {
+    const int npack = a.I / 4;
+    const int rpb = let_rpb(npack);
+    const unsigned grid = (unsigned)((a.O + rpb - 1) / rpb);
+#define L(TEAM, NV)                                                                                                   \
+    hipLaunchKernelGGL((k_let_fwd<TO, TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a, (TO*)out, scale_out, \
+                       rzp_out, wshift_out)
+    LET_DISPATCH(npack, L);
+#undef L
+}
+
+template <typename TG>
+static void let_bwd_launch(const LetArgs& a, const void* gout, const float* g_wshift, float* d_cs, float* d_rs, float* d_shift,
+                           float* d_up, float* d_low, float* ws, hipStream_t stream) {
+    const int npack = a.I / 4;
+    const int rpb = let_rpb(npack);
+    const unsigned grid = (unsigned)((a.O + rpb - 1) / rpb);
+    const bool cols = d_cs || d_shift;
+    RowCtx* rowctx = cols ? reinterpret_cast<RowCtx*>(ws) : nullptr;
+#define L(TEAM, NV)                                                                                                    \
+    hipLaunchKernelGGL((k_let_bwd_rows<TG, TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a, (const TG*)gout, \
+                       d_up, d_low, d_rs, rowctx)
+    LET_DISPATCH(npack, L);
+#undef L
+    if (!cols) return;
+    const int nchunk = let_chunks(a.O, a.I);
+    const int rpc = (int)((a.O + nchunk - 1) / nchunk);
+    float* part_cs = d_cs ? ws + 8 * a.O : nullptr;
+    float* part_sh = d_shift ? ws + 8 * a.O + (d_cs ? (long long)nchunk * a.I : 0) : nullptr;
+    const unsigned tiles = (unsigned)((npack + 63) / 64);
+    hipLaunchKernelGGL((k_let_bwd_cols<TG>), dim3(tiles, nchunk), dim3(256), 0, stream, a, (const TG*)gout, g_wshift, rowctx, rpc,
+                       part_cs, part_sh);
+    const unsigned fg = (unsigned)((a.I + 63) / 64);
+    if (d_cs) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, stream, part_cs, nchunk, a.I, d_cs);
+    if (d_shift) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, stream, part_sh, nchunk, a.I, d_shift);
+}
+
 }  // namespace miq
 
 using namespace miq;
 
-extern "C" int miq_let_partial_rows(int64_t O, int64_t I) {
+extern "C" int64_t miq_let_workspace(int64_t O, int64_t I) {
     if (O <= 0 || I <= 0 || I % 4) return 0;
-    const int rpb = let_rpb((int)(I / 4));
-    return let_grid(O, rpb) * rpb;
+    return 8 * O + 2ll * let_chunks(O, I) * I;
 }
 
 extern "C" int miq_let_rowquant_fwd(const float* w, const float* cs, const float* rs, int rs_div, const float* shift,
-                                    const float* up, const float* low, float* out, float* scale_out, float* rzp_out,
+                                    const float* up, const float* low, void* out, float* scale_out, float* rzp_out,
                                     float* wshift_out, int64_t O, int64_t I, int n_bits, int symmetric, int flags,
-                                    void* stream) {
+                                    int out_dtype, void* stream) {
     if (O == 0 || I == 0) return 0;
     LetArgs a{w, cs, rs, rs_div, shift, up, low, (flags >> 1) & 1, n_bits, symmetric, O, (int)I};
     MIQ_CHECK_ARG(I < (1ll << 31), "miq_let_rowquant_fwd: matrix too wide");
     if (int rc = let_check("miq_let_rowquant_fwd", a)) return rc;
     MIQ_CHECK_ARG(out && scale_out && rzp_out && is_aligned16(out), "miq_let_rowquant_fwd: null or unaligned output");
     MIQ_CHECK_ARG(!shift || wshift_out, "miq_let_rowquant_fwd: wshift_out required with shift");
-    const int npack = (int)(I / 4);
-    const int grid = let_grid(O, let_rpb(npack));
-#define L(TEAM, NV)                                                                                              \
-    hipLaunchKernelGGL((k_let_fwd<TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0, (hipStream_t)stream, a, out, \
-                       scale_out, rzp_out, wshift_out)
-    LET_DISPATCH(npack, L);
-#undef L
+    MIQ_CHECK_ARG(out_dtype == MIQ_F32 || out_dtype == MIQ_F16, "miq_let_rowquant_fwd: unsupported output dtype %d", out_dtype);
+    if (out_dtype == MIQ_F32) let_fwd_launch<float>(a, out, scale_out, rzp_out, wshift_out, (hipStream_t)stream);
+    else let_fwd_launch<__half>(a, out, scale_out, rzp_out, wshift_out, (hipStream_t)stream);
     MIQ_CHECK_LAUNCH("miq_let_rowquant_fwd");
     return 0;
 }
 
-extern "C" int miq_let_rowquant_bwd(const float* grad_out, const float* g_wshift, const float* w, const float* cs,
+extern "C" int miq_let_rowquant_bwd(const void* grad_out, const float* g_wshift, const float* w, const float* cs,
                                     const float* rs, int rs_div, const float* shift, const float* up, const float* low,
                                     float* d_cs, float* d_rs, float* d_shift, float* d_up, float* d_low, float* workspace,
-                                    int64_t O, int64_t I, int n_bits, int symmetric, int flags, void* stream) {
+                                    int64_t O, int64_t I, int n_bits, int symmetric, int flags, int grad_dtype, void* stream) {
     if (O == 0 || I == 0) return 0;
     LetArgs a{w, cs, rs, rs_div, shift, up, low, (flags >> 1) & 1, n_bits, symmetric, O, (int)I};
     MIQ_CHECK_ARG(I < (1ll << 31), "miq_let_rowquant_bwd: matrix too wide");
@@ -358,20 +448,9 @@ extern "C" int miq_let_rowquant_bwd(const float* grad_out, const float* g_wshift
     MIQ_CHECK_ARG(!d_rs || rs, "miq_let_rowquant_bwd: d_rs needs rs");
     MIQ_CHECK_ARG(!d_shift || (shift && g_wshift), "miq_let_rowquant_bwd: d_shift needs shift and g_wshift");
     MIQ_CHECK_ARG((!d_cs && !d_shift) || (workspace && is_aligned16(workspace)), "miq_let_rowquant_bwd: workspace required");
-    const int npack = (int)(I / 4);
-    const int rpb = let_rpb(npack);
-    const int grid = let_grid(O, rpb);
-    const long long prow = (long long)grid * rpb;
-    float* part_cs = d_cs ? workspace : nullptr;
-    float* part_sh = d_shift ? workspace + (d_cs ? prow * I : 0) : nullptr;
-#define L(TEAM, NV)                                                                                                  \
-    hipLaunchKernelGGL((k_let_bwd<TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0, (hipStream_t)stream, a, grad_out, \
-                       g_wshift, d_up, d_low, d_rs, part_cs, part_sh)
-    LET_DISPATCH(npack, L);
-#undef L
-    const unsigned fg = (unsigned)((I + 63) / 64);
-    if (d_cs) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, (hipStream_t)stream, part_cs, (int)prow, (int)I, d_cs);
-    if (d_shift) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, (hipStream_t)stream, part_sh, (int)prow, (int)I, d_shift);
+    MIQ_CHECK_ARG(grad_dtype == MIQ_F32 || grad_dtype == MIQ_F16, "miq_let_rowquant_bwd: unsupported gradient dtype %d", grad_dtype);
+    if (grad_dtype == MIQ_F32) let_bwd_launch<float>(a, grad_out, g_wshift, d_cs, d_rs, d_shift, d_up, d_low, workspace, (hipStream_t)stream);
+    else let_bwd_launch<__half>(a, grad_out, g_wshift, d_cs, d_rs, d_shift, d_up, d_low, workspace, (hipStream_t)stream);
     MIQ_CHECK_LAUNCH("miq_let_rowquant_bwd");
     return 0;
 }

@@ -147,7 +147,10 @@ class _BlockBase(nn.Module):
     def _let_linear(m, cs=None, rs=None, rs_div=True, shift=None):
         """temp_weight / temp_bias of one linear: quantize((W * cs) / rs or * rs); bias + W @ shift.
         The caller applies the row factor and the output shift to the bias (small vectors)."""
-        wq, wshift = m.weight_quantizer.forward_let(m.weight, cs, rs, rs_div, shift)
+        if cs is None and rs is None and shift is None:
+            wq, wshift = m.weight_quantizer(m.weight), None  # nothing to fuse: the plain row kernels are leaner
+        else:
+            wq, wshift = m.weight_quantizer.forward_let(m.weight, cs, rs, rs_div, shift)
         m.temp_weight = wq
         if wshift is None:
             m.temp_bias = m.bias

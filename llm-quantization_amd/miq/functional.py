@@ -354,17 +354,17 @@ def let_supported(w, group=0) -> bool:
             and w.shape[1] <= 16384 and w.is_contiguous())
 
 
-def let_rowquant_fwd(w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, preactivated=False):
+def let_rowquant_fwd(w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, preactivated=False, out_dtype=None):
     dev = L.check_gpu(w, cs, rs, shift, up, low)
     O, I = w.shape
-    out = torch.empty_like(w)
+    out = torch.empty_like(w, dtype=out_dtype or w.dtype)
     scale = torch.empty((O, 1), dtype=w.dtype, device=dev)
     rzp = torch.empty_like(scale)
     wshift = torch.empty(O, dtype=w.dtype, device=dev) if shift is not None else None
     with torch.cuda.device(dev):
         L.call("miq_let_rowquant_fwd", L.ptr(w), L.ptr(cs), L.ptr(rs), L.i32(int(bool(rs_div))), L.ptr(shift), L.ptr(up),
                L.ptr(low), L.ptr(out), L.ptr(scale), L.ptr(rzp), L.ptr(wshift), L.i64(O), L.i64(I), L.i32(int(n_bits)),
-               L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)), L.stream_of(w))
+               L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(out)), L.stream_of(w))
     return out, wshift, scale, rzp
 
 
@@ -380,25 +380,28 @@ def let_rowquant_bwd(g, g_wshift, w, cs, rs, rs_div, shift, up, low, n_bits, sym
     d_shift = torch.empty_like(shift) if want_shift else None
     d_up = torch.empty_like(up) if up is not None else None
     d_low = torch.empty_like(low) if low is not None else None
-    prow = int(L.lib().miq_let_partial_rows(L.i64(O), L.i64(I)))
-    nws = prow * I * (int(want_cs) + int(want_shift))
-    ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
+    ws = None
+    if want_cs or want_shift:
+        ws = torch.empty(int(L.lib().miq_let_workspace(L.i64(O), L.i64(I))), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         L.call("miq_let_rowquant_bwd", L.ptr(g), L.ptr(g_wshift), L.ptr(w), L.ptr(cs), L.ptr(rs), L.i32(int(bool(rs_div))),
                L.ptr(shift), L.ptr(up), L.ptr(low), L.ptr(d_cs), L.ptr(d_rs), L.ptr(d_shift), L.ptr(d_up), L.ptr(d_low),
                L.ptr(ws), L.i64(O), L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
-               L.i32(_flags(False, preactivated)), L.stream_of(w))
+               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(g)), L.stream_of(w))
     return d_cs, d_rs, d_shift, d_up, d_low
 
 
 class LetRowFQ(torch.autograd.Function):
-    """(wq, wshift, scale, rzp) = quantize((w * cs) / rs or * rs), wshift = w @ shift; w is a constant."""
+    """(wq, wshift, scale, rzp) = quantize((w * cs) / rs or * rs), wshift = w @ shift; w is a constant.
+    ``half_out``: store wq in fp16 (for consumers that would cast it anyway, i.e. linears under autocast);
+    the incoming gradient is then fp16 too and is read as such."""
 
     @staticmethod
-    def forward(ctx, w, cs, rs, rs_div, shift, up, low, n_bits, symmetric):
+    def forward(ctx, w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, half_out=False):
         flat = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
         csf, rsf, shf = flat(cs), flat(rs), flat(shift)
-        out, wshift, scale, rzp = let_rowquant_fwd(w, csf, rsf, rs_div, shf, up, low, n_bits, symmetric)
+        out, wshift, scale, rzp = let_rowquant_fwd(w, csf, rsf, rs_div, shf, up, low, n_bits, symmetric,
+                                                   out_dtype=torch.float16 if half_out else None)
         ctx.save_for_backward(w, csf, rsf, shf, up, low)
         ctx.cfg = (bool(rs_div), int(n_bits), bool(symmetric))
         ctx.shapes = tuple(None if t is None else t.shape for t in (cs, rs, shift))
@@ -418,7 +421,7 @@ class LetRowFQ(torch.autograd.Function):
                                                             symmetric, want_cs=need[1], want_rs=need[2], want_shift=need[4])
         shp = ctx.shapes
         rs_ = lambda t, s: None if t is None else t.reshape(s)
-        return None, rs_(d_cs, shp[0]), rs_(d_rs, shp[1]), None, rs_(d_shift, shp[2]), d_up, d_low, None, None
+        return None, rs_(d_cs, shp[0]), rs_(d_rs, shp[1]), None, rs_(d_shift, shp[2]), d_up, d_low, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

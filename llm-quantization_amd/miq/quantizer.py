@@ -156,7 +156,10 @@ class UniformAffineQuantizer(nn.Module):
         without materialising it, and return it with w @ shift (None without ``shift``).  Same result
         as forward() on the materialised tensor; gradients reach cs, rs, shift and the LWC factors."""
         up, low = self._lwc_params(w)
-        out, wshift, scale, rzp = F.LetRowFQ.apply(w, cs, rs, bool(rs_div), shift, up, low, self.n_bits, bool(self.symmetric))
+        # under autocast the consuming linear casts the weight to fp16: let the kernel store that directly
+        half_out = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16
+        out, wshift, scale, rzp = F.LetRowFQ.apply(w, cs, rs, bool(rs_div), shift, up, low, self.n_bits, bool(self.symmetric),
+                                                   half_out)
         self.scale = scale
         self.round_zero_point = rzp
         return out, (wshift if shift is not None else None)

@@ -110,3 +110,20 @@ def test_autograd_function_and_fallback_predicate():
     for a, b, k in zip(got, ref, p):
         assert a.shape == b.shape and rel_err(a.cpu(), b.cpu()) <= 2e-5, k
     assert F.let_supported(w) and not F.let_supported(w.half()) and not F.let_supported(w[:, :510]) and not F.let_supported(w, 128)
+
+
+def test_half_output_and_half_gradient_are_casts():
+    """out_dtype fp16 == the fp32 result cast to fp16; an fp16 incoming gradient gives exactly the
+    gradients of the same values in fp32 (the kernels convert on load)."""
+    d = make(512, 4096, True, "div", True, True, 901)
+    dev = lambda x: None if x is None else x.to(DEV)
+    args = (dev(d["w"]), dev(d["cs"]), dev(d["rs"]), True, dev(d["shift"]), dev(d["up"]), dev(d["low"]), 4, False)
+    out32, ws32, s32, z32 = F.let_rowquant_fwd(*args)
+    out16, ws16, s16, z16 = F.let_rowquant_fwd(*args, out_dtype=torch.float16)
+    assert out16.dtype == torch.float16 and torch.equal(out16, out32.half())
+    assert torch.equal(s16, s32) and torch.equal(z16, z32) and torch.equal(ws16, ws32)
+    g16 = dev(d["g"]).half()
+    a = F.let_rowquant_bwd(g16, dev(d["gb"]), *args[:3], True, *args[4:])
+    b = F.let_rowquant_bwd(g16.float(), dev(d["gb"]), *args[:3], True, *args[4:])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
