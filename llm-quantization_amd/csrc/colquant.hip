@@ -330,6 +330,9 @@ static int launch_gather(const void* x, const int* idx, void* out, long long R, 
     int rows = (int)(65536 / row_bytes);
     if (rows < 1) rows = 1;
     if (rows > 16) rows = 16;
+    // at least ~1024 blocks when the slab has that many rows: several small tiles per CU stream better than one big one
+    const long long want_rows = R / 1024;
+    if (rows > want_rows) rows = (int)(want_rows < 1 ? 1 : want_rows);
     if (rows > R) rows = (int)R;
     const size_t lds = (size_t)rows * row_bytes;
     const unsigned grid = (unsigned)((R + rows - 1) / rows);

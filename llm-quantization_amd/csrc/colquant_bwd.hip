@@ -55,11 +55,15 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
             }
         };
         long long r = r0 + w;
-        for (; r + 4 < r1; r += 8) {
+        for (; r + 12 < r1; r += 16) {
             Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
             Pack<T, VEC> a1 = ld_pack<T, VEC>(x + (r + 4) * C + col0), b1 = ld_pack<T, VEC>(g + (r + 4) * C + col0);
+            Pack<T, VEC> a2 = ld_pack<T, VEC>(x + (r + 8) * C + col0), b2 = ld_pack<T, VEC>(g + (r + 8) * C + col0);
+            Pack<T, VEC> a3 = ld_pack<T, VEC>(x + (r + 12) * C + col0), b3 = ld_pack<T, VEC>(g + (r + 12) * C + col0);
             body(a0, b0);
             body(a1, b1);
+            body(a2, b2);
+            body(a3, b3);
         }
         for (; r < r1; r += 4) {
             Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
@@ -87,32 +91,27 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
 // w, w+4, ...; every block only touches its own 64 columns, so folding in place is race-free once
 // all of the block's reads are done (the barrier).
 __global__ void __launch_bounds__(256) k_colbwd_fold(float* __restrict__ part, int nchunk, int C) {
-    __shared__ float sm[3][4][64];
+    __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int k = blockIdx.y;  // plane: dS, #max, #min
     const bool valid = c < C;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        if (valid) {
-            const float* p = part + ((long long)k * nchunk) * C + c;
-            int j = w;
-            for (; j + 12 < nchunk; j += 16) {
-                v0 += p[(long long)j * C];
-                v1 += p[(long long)(j + 4) * C];
-                v2 += p[(long long)(j + 8) * C];
-                v3 += p[(long long)(j + 12) * C];
-            }
-            for (; j < nchunk; j += 4) v0 += p[(long long)j * C];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (valid) {
+        const float* p = part + ((long long)k * nchunk) * C + c;
+        int j = w;
+        for (; j + 12 < nchunk; j += 16) {
+            v0 += p[(long long)j * C];
+            v1 += p[(long long)(j + 4) * C];
+            v2 += p[(long long)(j + 8) * C];
+            v3 += p[(long long)(j + 12) * C];
         }
-        sm[k][w][lane] = (v0 + v1) + (v2 + v3);
+        for (; j < nchunk; j += 4) v0 += p[(long long)j * C];
     }
+    sm[w][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
-    if (w == 0 && valid) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            part[((long long)k * nchunk) * C + c] = (sm[k][0][lane] + sm[k][1][lane]) + (sm[k][2][lane] + sm[k][3][lane]);
-    }
+    if (w == 0 && valid)
+        part[((long long)k * nchunk) * C + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 // one block per cluster (+1 for un-clustered channels): per-channel shares for the max / min elements
@@ -204,11 +203,15 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
         st_pack<T, VEC>(dx + r * C + col0, o);
     };
     long long r = r0 + w;
-    for (; r + 4 < r1; r += 8) {
+    for (; r + 12 < r1; r += 16) {
         Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
         Pack<T, VEC> a1 = ld_pack<T, VEC>(x + (r + 4) * C + col0), b1 = ld_pack<T, VEC>(g + (r + 4) * C + col0);
+        Pack<T, VEC> a2 = ld_pack<T, VEC>(x + (r + 8) * C + col0), b2 = ld_pack<T, VEC>(g + (r + 8) * C + col0);
+        Pack<T, VEC> a3 = ld_pack<T, VEC>(x + (r + 12) * C + col0), b3 = ld_pack<T, VEC>(g + (r + 12) * C + col0);
         body(a0, b0, r);
         body(a1, b1, r + 4);
+        body(a2, b2, r + 8);
+        body(a3, b3, r + 12);
     }
     for (; r < r1; r += 4) {
         Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
@@ -239,7 +242,7 @@ static int colquant_bwd_t(const void* g, const void* x, const void* scale, const
         else
             hipLaunchKernelGGL((k_colbwd_stats<T, 1>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
                                (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
-        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, part, nchunk, (int)C);
+        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64), 3), dim3(256), 0, stream, part, nchunk, (int)C);
     }
     if (phase == 1) {
         MIQ_CHECK_LAUNCH("miq_colquant_bwd");
