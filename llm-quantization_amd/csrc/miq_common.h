@@ -324,6 +324,9 @@ __device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, l
 // ---------------------------------------------------------------------------------------------
 // Host-side launch helper: pick (TEAM, NV) from the number of 16-byte packs in the longest row.
 // ---------------------------------------------------------------------------------------------
+// Teams that are not powers of two (384 x 8 for 11008-wide rows, 320 x 4, 448 x 8, 896 x 8) remove the idle
+// lanes of the next larger tile but were measured slower in the backward kernels (6 or 7 waves per block
+// spread unevenly over the 4 SIMDs), so the table stays with power-of-two teams.
 #define MIQ_ROW_DISPATCH(NPACK, LAUNCH)                                  \
     do {                                                                 \
         if ((NPACK) <= 16) { LAUNCH(16, 1); }                            \

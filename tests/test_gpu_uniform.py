@@ -183,3 +183,22 @@ def test_empty_and_errors():
         F.rowquant_uniform_fwd(torch.zeros(4, 8, device=DEV), 1, False)  # n_bits out of range
     with pytest.raises(MiqError):
         F.rowquant_uniform_fwd(torch.zeros(4, 8, device=DEV, dtype=torch.bfloat16), 4, False)
+
+
+@pytest.mark.parametrize("I,dt", [(5120, "f32"), (11008, "f32"), (13824, "f32"), (28672, "f32"), (28672, "f16"), (11008, "f16")])
+def test_backward_at_llama_row_widths(I, dt):
+    """Row widths that leave part of the widest register tiles idle (5120 ... 28672): gradients vs the oracle."""
+    dtype = DT[dt]
+    O_ = 48
+    x = synth.weight(O_, I, 40, dtype)
+    up, low = synth.lwc_factors(O_, 41, dtype)
+    g = synth.grad_like(x, 42)
+    xr, ur, lr = (t.clone().requires_grad_(True) for t in (x, up, low))
+    r = O.uniform_row(xr, 4, False, ur, lr)
+    ref = torch.autograd.grad((r.out.float() * g.float()).sum(), [xr, ur, lr])
+    dx, d_up, d_low = F.rowquant_uniform_bwd(g.to(DEV), x.to(DEV), 4, False, up.to(DEV), low.to(DEV))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, b, name in zip((dx, d_up, d_low), ref, ("dx", "d_up", "d_low")):
+        ok = torch.isfinite(b)
+        z = torch.zeros_like(b)
+        assert rel_err(torch.where(ok, a.cpu(), z).float(), torch.where(ok, b, z).float()) <= 4 * tol, name
