@@ -128,6 +128,11 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
         if (dead) return 0.f;
         return (((kLn2 * el.lvl) * gq) / kLn2 / el.mag) * el.sign;
     };
+    // The per-element gradient w.r.t. x/s is needed again for dx: keep it instead of redoing the log2 / level
+    // search.  fp32 reuses the registers of g (not read again); fp16 uses a side array while it fits.
+    constexpr bool kInPlace = sizeof(T) == 4;
+    constexpr bool kSide = !kInPlace && NV * VEC <= 32;
+    float side[kSide ? NV * VEC : 1];
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -137,6 +142,8 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
             const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
             const Exp2Elem el = exp2_elem<T>(xv, c, dv);
             const float gqq = grad_q(gv, el);
+            if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(gqq);
+            if constexpr (kSide) side[k * VEC + e] = gqq;
             acc[0] += gv * el.signed_lvl + gqq * (-xv / (c.s * c.s));
             acc[1] += (xv == rmax) ? 1.f : 0.f;
             acc[2] += (xv == rmin) ? 1.f : 0.f;
@@ -162,7 +169,11 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-                float d = grad_q(gv, exp2_elem<T>(xv, c, dv)) / c.s;
+                float gqq;
+                if constexpr (kInPlace) gqq = gv;  // overwritten above
+                else if constexpr (kSide) gqq = side[k * VEC + e];
+                else gqq = grad_q(gv, exp2_elem<T>(xv, c, dv));
+                float d = gqq / c.s;
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);
@@ -283,6 +294,9 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
         if (!live) return 0.f;
         return ((kLn2 * el.p) * ((gv * c.s) * el.sign)) / (el.mag * kLn2) * sgnf(el.u);
     };
+    constexpr bool kInPlace = sizeof(T) == 4;  // see k_exp2_bwd
+    constexpr bool kSide = !kInPlace && NV * VEC <= 32;
+    float side[kSide ? NV * VEC : 1];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};  // d_s, d_mid, #max, #min
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -292,6 +306,8 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
             const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
             const Exp1Elem el = exp1_elem<T>(xv, c, dv);
             const float du = d_u(gv, el);
+            if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(du);
+            if constexpr (kSide) side[k * VEC + e] = du;
             acc[0] += gv * (el.p * el.sign) + du * (-el.v / (c.s * c.s));
             acc[1] += gv - du / c.s;
             acc[2] += (xv == rmax) ? 1.f : 0.f;
@@ -324,7 +340,11 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-                float d = d_u(gv, exp1_elem<T>(xv, c, dv)) / c.s;
+                float du;
+                if constexpr (kInPlace) du = gv;  // overwritten above
+                else if constexpr (kSide) du = side[k * VEC + e];
+                else du = d_u(gv, exp1_elem<T>(xv, c, dv));
+                float d = du / c.s;
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);

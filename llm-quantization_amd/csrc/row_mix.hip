@@ -130,6 +130,7 @@ k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restr
     row_minmax(x, padded, lds, rmin, rmax);
     const MixCtx c = mix_ctx(a, row, rmin, rmax);
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dS_lo, dS_hi, over_lo, over_hi, #max, #min
+    // returns the straight-through part of dx through this grid (what autograd forms as ((g*w)*s)/s)
     auto terms = [&](float xv, float gv, const Grid& gr, float& dS, float& over) {
         const float gb = gv * gr.w;
         const float q = xv / gr.s;
@@ -138,6 +139,7 @@ k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restr
         const float xd = clampf(xi, 0.f, gr.Q) - gr.z;
         dS += gb * (xd - (m ? q : 0.f));
         if (xi > gr.Q) over += gb * gr.s;
+        return m ? (gb * gr.s) / gr.s : 0.f;
     };
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -145,8 +147,10 @@ k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restr
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float xv = x.v[k].e[e], gv = g.v[k].e[e];
-            terms(xv, gv, c.lo, acc[0], acc[2]);
-            terms(xv, gv, c.hi, acc[1], acc[3]);
+            float d = 0.f;
+            d += terms(xv, gv, c.lo, acc[0], acc[2]);
+            d += terms(xv, gv, c.hi, acc[1], acc[3]);
+            g.v[k].e[e] = d;  // g is not read again: its registers carry the direct gradient to the dx pass
             acc[4] += (xv == rmax) ? 1.f : 0.f;
             acc[5] += (xv == rmin) ? 1.f : 0.f;
         }
@@ -187,16 +191,8 @@ k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restr
             Pack<float, VEC> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const float xv = x.v[k].e[e], gv = g.v[k].e[e];
-                float d = 0.f;
-                {
-                    const float xi = grid_level(xv, c.lo);
-                    if (xi >= 0.f && xi <= c.lo.Q) d += ((gv * c.lo.w) * c.lo.s) / c.lo.s;
-                }
-                {
-                    const float xi = grid_level(xv, c.hi);
-                    if (xi >= 0.f && xi <= c.hi.Q) d += ((gv * c.hi.w) * c.hi.s) / c.hi.s;
-                }
+                const float xv = x.v[k].e[e];
+                float d = g.v[k].e[e];
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
                 o.e[e] = d;
