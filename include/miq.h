@@ -149,6 +149,19 @@ int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int6
                        void* stream);
 
 /*
+ * RPTQ reorder gather fused into LayerNorm, forward (OmniLayerNorm.forward with a reorder index,
+ * quantize/omni_norm.py:29-42: index_select on the last axis, then layer_norm):
+ *   out[r, c] = (x[r, idx[c]] - mean_r) * rstd_r * weight[c] + bias[c]
+ * with mean / biased variance over the C channels of row r in fp32 and rstd = 1/sqrt(var + eps).
+ * idx NULL = plain LayerNorm; weight / bias may be NULL.  x, out: [R, C] of x_dtype / out_dtype
+ * (fp16 in -> fp32 out is what autocast produces); weight, bias: [C] of w_dtype; mean_out, rstd_out:
+ * optional fp32 [R] (the saved statistics of a LayerNorm backward).  C % 4 == 0.
+ */
+int miq_gather_layernorm_fwd(const void* x, const int* idx, const void* weight, const void* bias, void* out,
+                             float* mean_out, float* rstd_out, int64_t R, int64_t C, float eps, int x_dtype,
+                             int w_dtype, int out_dtype, void* stream);
+
+/*
  * Exponential/log weight quantizer v2 (levels 0, +-1, +-2, ..., +-2^(2^(n-1)-2)), n_bits in [2, 4].
  * Replaces ExpAffineQuantizer.per_channel_dynamic_calibration + FakeQuant.forward / backward
  * (quantize/quantizer_exp_v2.py:186-204, :21-62, :65-105 — the backward is the reference's own

@@ -295,6 +295,69 @@ class GatherLastDim(torch.autograd.Function):
         return gather_lastdim(g.contiguous(), inv), None, None
 
 
+def gather_layernorm_supported(x, weight, bias) -> bool:
+    C = x.shape[-1]
+    # hidden sizes only: for wider rows (measured at 11008 fp16) gather + ATen's LayerNorm is as fast
+    ok = x.is_cuda and x.dtype in (torch.float16, torch.float32) and C % 4 == 0 and C <= 8192
+    for t in (weight, bias):
+        ok = ok and (t is None or (t.is_cuda and t.dtype in (torch.float16, torch.float32) and t.numel() == C))
+    if weight is not None and bias is not None:
+        ok = ok and weight.dtype == bias.dtype
+    return bool(ok)
+
+
+def gather_layernorm_fwd(x, idx_i32, weight, bias, eps: float, out_dtype=None):
+    """(y, mean, rstd): y = layer_norm(index_select(x, -1, idx)) in one pass; mean / rstd fp32 [..., 1]."""
+    dev = L.check_gpu(x, idx_i32, weight, bias)
+    C = x.shape[-1]
+    R = x.numel() // C if C else 0
+    out = torch.empty_like(x, dtype=out_dtype or x.dtype)
+    stat_shape = tuple(x.shape[:-1]) + (1,)
+    mean = torch.empty(stat_shape, dtype=torch.float32, device=dev)
+    rstd = torch.empty(stat_shape, dtype=torch.float32, device=dev)
+    wb = weight if weight is not None else bias
+    w_code = L._DT[wb.dtype] if wb is not None else L.F32
+    with torch.cuda.device(dev):
+        L.call("miq_gather_layernorm_fwd", L.ptr(x), L.ptr(idx_i32), L.ptr(weight), L.ptr(bias), L.ptr(out), L.ptr(mean),
+               L.ptr(rstd), L.i64(R), L.i64(C), L.f32(float(eps)), L.i32(L.dtype_code(x)), L.i32(w_code),
+               L.i32(L.dtype_code(out)), L.stream_of(x))
+    return out, mean, rstd
+
+
+class GatherLayerNorm(torch.autograd.Function):
+    """layer_norm(index_select(x, -1, idx), weight, bias): fused forward kernel; the backward recomputes the
+    gathered row with the gather kernel, uses ATen's LayerNorm backward on the saved mean / rstd and routes
+    dx back through the inverse permutation."""
+
+    @staticmethod
+    def forward(ctx, x, idx_i32, inv_i32, weight, bias, eps, out_dtype):
+        x = x.contiguous()
+        w = None if weight is None else weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        y, mean, rstd = gather_layernorm_fwd(x, idx_i32, w, b, eps, out_dtype)
+        ctx.save_for_backward(x, idx_i32, inv_i32, w, b, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, idx, inv, w, b, mean, rstd = ctx.saved_tensors
+        xg = gather_lastdim(x, idx) if idx is not None else x
+        cdt = gy.dtype
+        mask = [ctx.needs_input_grad[0], w is not None and ctx.needs_input_grad[3], b is not None and ctx.needs_input_grad[4]]
+        dxg, dw, db = torch.ops.aten.native_layer_norm_backward(
+            gy.contiguous(), xg.to(cdt), [x.shape[-1]], mean, rstd, None if w is None else w.to(cdt),
+            None if b is None else b.to(cdt), mask)
+        dx = None
+        if mask[0]:
+            dxg = dxg.to(x.dtype)
+            dx = gather_lastdim(dxg.contiguous(), inv) if idx is not None else dxg
+        if dw is not None and w is not None:
+            dw = dw.to(w.dtype)
+        if db is not None and b is not None:
+            db = db.to(b.dtype)
+        return dx, None, None, dw if mask[1] else None, db if mask[2] else None, None, None
+
+
 class ActEvalFQ(torch.autograd.Function):
     """Frozen per-channel scales: out = fq(x); dx = g * [level inside the grid]."""
 

@@ -25,6 +25,7 @@ class OmniLayerNorm(nn.Module):
         self.normalized_shape = ori_layer_norm.normalized_shape
         self.use_temporary_parameter = False
         self._perm = None  # (source tensor id, int32 index, int32 inverse) cached on the device
+        self.fused_gather = True  # gather + LayerNorm in one kernel when a reorder index is registered
 
     def _permutation(self, device):
         idx = self.reorder_index
@@ -45,6 +46,13 @@ class OmniLayerNorm(nn.Module):
             bias = self.bias
         if hasattr(self, "reorder_index") and x.ndim in (2, 3):
             i32, inv = self._permutation(x.device)
+            if (self.fused_gather and tuple(self.normalized_shape) == (x.shape[-1],)
+                    and F.gather_layernorm_supported(x, weight, bias)):
+                # one pass: gather + normalisation.  Under autocast PyTorch runs layer_norm in fp32.
+                amp = torch.is_autocast_enabled()
+                out_dtype = torch.float32 if amp else (weight.dtype if weight is not None else x.dtype)
+                if amp or weight is None or weight.dtype == x.dtype:
+                    return F.GatherLayerNorm.apply(x, i32, inv, weight, bias, self.eps, out_dtype)
             x = F.GatherLastDim.apply(x, i32, inv)
         return self.norm_func(x, self.normalized_shape, weight, bias, eps=self.eps)
 
