@@ -216,7 +216,7 @@ def cpu_baseline(threads: int):
         once()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 12.0 or n >= 20:
+        if dt > 12.0 or n >= 100:
             break
     nbytes = (2 + 3) * w.numel() * 4 + (3 + 3) * a.numel() * 4
     return {"value": round(nbytes * n / dt / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
