@@ -9,6 +9,7 @@
 // Semantics: UniformAffineQuantizer.per_cluster_minmax_calibration / per_tensor_minmax_calibration /
 // calibration / fake_quant (reference quantize/quantizer.py:157-238,99-121) and the index_select in
 // OmniLayerNorm.forward (quantize/omni_norm.py:36-40).
+#include <type_traits>
 #include "miq_common.h"
 
 namespace miq {
@@ -206,34 +207,41 @@ k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __
     }
     // wave-uniform: every integer intermediate of this wave's channels is exact in T
     const bool exact_int = __all(ok);
-    auto body = [&](const Pack<T, VEC>& a, long long r) {
-        Pack<T, VEC> o;
-        Pack<uint8_t, VEC> cd;
+    // the streaming loop is instantiated for both values of exact_int: a per-element test of it would
+    // become a scalar branch around every fp16 re-rounding
+    auto stream_rows = [&](auto exact_tag) {
+        constexpr bool EX = decltype(exact_tag)::value;
+        auto body = [&](const Pack<T, VEC>& a, long long r) {
+            Pack<T, VEC> o;
+            Pack<uint8_t, VEC> cd;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xi = col_level<T>(to_f<T>(a.e[e]), s[e], rs[e], z[e], exact_int);
-            const float xc = clampf(xi, 0.f, qmax);
-            o.e[e] = from_f<T>(affine_dequant<T>(xc, s[e], z[e], exact_int));
-            if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+            for (int e = 0; e < VEC; ++e) {
+                const float xi = col_level<T>(to_f<T>(a.e[e]), s[e], rs[e], z[e], EX);
+                const float xc = clampf(xi, 0.f, qmax);
+                o.e[e] = from_f<T>(affine_dequant<T>(xc, s[e], z[e], EX));
+                if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+            }
+            st_pack<T, VEC>(out + r * C + col0, o);
+            if (codes) st_pack<uint8_t, VEC>(codes + r * C + col0, cd);
+        };
+        long long r = r0 + w;
+        for (; r + 12 < r1; r += 16) {
+            Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
+            Pack<T, VEC> b = ld_pack<T, VEC>(x + (r + 4) * C + col0);
+            Pack<T, VEC> c = ld_pack<T, VEC>(x + (r + 8) * C + col0);
+            Pack<T, VEC> d = ld_pack<T, VEC>(x + (r + 12) * C + col0);
+            body(a, r);
+            body(b, r + 4);
+            body(c, r + 8);
+            body(d, r + 12);
         }
-        st_pack<T, VEC>(out + r * C + col0, o);
-        if (codes) st_pack<uint8_t, VEC>(codes + r * C + col0, cd);
+        for (; r < r1; r += 4) {
+            Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
+            body(a, r);
+        }
     };
-    long long r = r0 + w;
-    for (; r + 12 < r1; r += 16) {
-        Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
-        Pack<T, VEC> b = ld_pack<T, VEC>(x + (r + 4) * C + col0);
-        Pack<T, VEC> c = ld_pack<T, VEC>(x + (r + 8) * C + col0);
-        Pack<T, VEC> d = ld_pack<T, VEC>(x + (r + 12) * C + col0);
-        body(a, r);
-        body(b, r + 4);
-        body(c, r + 8);
-        body(d, r + 12);
-    }
-    for (; r < r1; r += 4) {
-        Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
-        body(a, r);
-    }
+    if (sizeof(T) == 4 || exact_int) stream_rows(std::true_type{});
+    else stream_rows(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 // Semantics follow UniformAffineQuantizer.per_token_dynamic_calibration + fake_quant
 // (reference quantize/quantizer.py:248-273,99-121) and Mix2AffineQuantizer.forward
 // (quantize/quantizer_mix_v2.py:116-146) when per-row bit-widths are supplied.
+#include <type_traits>
 #include "miq_common.h"
 
 namespace miq {
@@ -104,22 +105,28 @@ k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ sc
     }
     const Divisor<T> dv(c.s);
     const bool exact_int = ints_exact<T>(c.rzp, c.qmax);
+    // instantiated for both values of exact_int (a per-element test would be a branch around every fp16 re-rounding)
+    auto quantize_row = [&](auto exact_tag) {
+        constexpr bool EX = decltype(exact_tag)::value;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
-        Pack<T, VEC> o;
-        Pack<uint8_t, VEC> cd;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            Pack<T, VEC> o;
+            Pack<uint8_t, VEC> cd;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xi = quant_level<T>(to_f<T>(x.v[k].e[e]), dv, c, exact_int);
-            const float xc = clampf(xi, 0.f, c.qmax);
-            o.e[e] = from_f<T>(affine_dequant<T>(xc, c.s, c.rzp, exact_int));
-            if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+            for (int e = 0; e < VEC; ++e) {
+                const float xi = quant_level<T>(to_f<T>(x.v[k].e[e]), dv, c, EX);
+                const float xc = clampf(xi, 0.f, c.qmax);
+                o.e[e] = from_f<T>(affine_dequant<T>(xc, c.s, c.rzp, EX));
+                if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+            }
+            const long long off = base + x.offset(k);
+            st_pack<T, VEC>(out + off, o);
+            if (codes) st_pack<uint8_t, VEC>(codes + off, cd);
         }
-        const long long off = base + x.offset(k);
-        st_pack<T, VEC>(out + off, o);
-        if (codes) st_pack<uint8_t, VEC>(codes + off, cd);
-    }
+    };
+    if (sizeof(T) == 4 || exact_int) quantize_row(std::true_type{});
+    else quantize_row(std::false_type{});
 }
 
 // Backward.  With m = [0 <= round(x/s)+zp <= qmax] and xd = clamp(..) - zp:
@@ -158,25 +165,30 @@ k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restri
     float acc[3] = {0.f, 0.f, 0.f};  // dS, #elements == rmax, #elements == rmin
     static_assert(NV * VEC <= 64, "mask of un-clamped elements is one 64-bit word");
     unsigned long long inside = 0ull;  // bit k*VEC+e: the level of element (k, e) lies inside the grid
+    auto row_sums = [&](auto exact_tag) {
+        constexpr bool EX = decltype(exact_tag)::value;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xv = to_f<T>(x.v[k].e[e]);
-            const float gv = to_f<T>(g.v[k].e[e]);
-            const float q = dv.div(xv);
-            const float xi = quant_level<T>(xv, dv, c, exact_int);
-            const bool m = (xi >= 0.f) && (xi <= c.qmax);
-            const float xd = clampf(xi, 0.f, c.qmax) - c.rzp;
-            acc[0] += gv * (xd - (m ? q : 0.f));
-            inside |= (m ? 1ull : 0ull) << (k * VEC + e);
-            if (WANT_DX) {
-                acc[1] += (xv == rmax) ? 1.f : 0.f;
-                acc[2] += (xv == rmin) ? 1.f : 0.f;
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = to_f<T>(x.v[k].e[e]);
+                const float gv = to_f<T>(g.v[k].e[e]);
+                const float q = dv.div(xv);
+                const float xi = quant_level<T>(xv, dv, c, EX);
+                const bool m = (xi >= 0.f) && (xi <= c.qmax);
+                const float xd = clampf(xi, 0.f, c.qmax) - c.rzp;
+                acc[0] += gv * (xd - (m ? q : 0.f));
+                inside |= (m ? 1ull : 0ull) << (k * VEC + e);
+                if (WANT_DX) {
+                    acc[1] += (xv == rmax) ? 1.f : 0.f;
+                    acc[2] += (xv == rmin) ? 1.f : 0.f;
+                }
             }
         }
-    }
+    };
+    if (sizeof(T) == 4 || exact_int) row_sums(std::true_type{});
+    else row_sums(std::false_type{});
     team_sum<TEAM, 3>(acc, lds);
     if (WANT_DX && padded) {
         const float npad = (float)(geo.g - len);
