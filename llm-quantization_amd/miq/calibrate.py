@@ -51,6 +51,7 @@ class CalibConfig:
     weight_mix_quant: bool = False
     loss_size_coef: float = 0.0
     use_shift: bool = True
+    aug_loss: bool = False                 # add the MSE against the fp block applied to the QUANTIZED model's inputs
 
 
 class LossScaler:
@@ -242,12 +243,14 @@ def _now(dev):
 
 def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfig, act_scales=None, act_shifts=None,
                     layer_prefix: str = "model.decoder.layers.0", dims=None, dp: Optional[DPContext] = None,
-                    position_ids=None, logger=None, reorder_stats_layer=None, indices=None, is_llama=False):
+                    position_ids=None, logger=None, reorder_stats_layer=None, indices=None, is_llama=False,
+                    resume_state=None):
     """Calibrate ONE block in place.
 
     quant_inps / fp_inps: [n_local, T, H] tensors holding THIS rank's shard of the calibration
     samples (all samples when dp is None); both are overwritten with the block's outputs, as the
-    reference does.  ``dims`` = (hidden, ffn, heads) is needed when reordering.
+    reference does.  ``dims`` = (hidden, ffn, heads) is needed when reordering.  ``resume_state``: the
+    layer's entry of a previous run's omni_parameters (reference ``--resume``, omniquant.py:452-453).
     Returns a dict with the per-step losses / gradient norms and the reorder indices.
     """
     dp = dp or DPContext()
@@ -300,14 +303,20 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
             with torch.no_grad():
                 qlayer.float()  # fp32 path: without autocast the block must match the fp32 activations
         with torch.no_grad(), (torch.autocast("cuda", dtype=torch.float16) if use_amp else nullcontext()):
+            if cfg.aug_loss:  # omniquant.py:405-406
+                fp_inps_2 = torch.empty_like(fp_inps)
             for j in range(n_local):
                 fp_inps[j] = qlayer(fp_inps[j].unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]
+                if cfg.aug_loss:
+                    fp_inps_2[j] = qlayer(quant_inps[j].unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]
 
     lap("fp_targets")
     qlayer.set_quant_state(weight_quant=False, act_quant=True)  # weights are quantized by hand before each forward
     qlayer.let = cfg.let
     if cfg.let:
         init_let(qlayer, act_scales, act_shifts, layer_prefix, cfg, indices, dtype, dev, is_llama)
+    if resume_state is not None:
+        qlayer.load_state_dict({k: v.to(dev) for k, v in resume_state.items()}, strict=False)
     _set_dp(qlayer, dp)
 
     losses: List[float] = []
@@ -337,6 +346,8 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                     qlayer.smooth_and_quant_temporary()
                     out = qlayer(quant_inps[i0:i0 + cfg.batch_size], attention_mask=mask_batch, position_ids=position_ids)[0]
                     loss = loss_func(fp_inps[i0:i0 + cfg.batch_size], out)
+                    if cfg.aug_loss:
+                        loss = loss + loss_func(fp_inps_2[i0:i0 + cfg.batch_size], out)
                     if cfg.weight_mix_quant:
                         ms, ts = qlayer.get_size_loss()
                         loss = loss + loss_func(ms, ts) * loss_size_coef

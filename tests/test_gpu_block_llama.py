@@ -134,3 +134,28 @@ def test_fused_let_step_equals_unfused_step(kind):
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     for n in g0:
         assert rel_err(g1[n].cpu(), g0[n].cpu()) <= 1e-4, (n, rel_err(g1[n].cpu(), g0[n].cpu()))
+
+
+def test_aug_loss_and_resume():
+    """aug_loss adds the MSE against the fp block applied to the quantized model's inputs: for a first
+    layer both inputs coincide, so the first loss doubles exactly.  resume_state reloads learned
+    parameters before training (reference --resume)."""
+    import dataclasses
+    d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+    m = d["meta"]
+    act_scales = {f"{PREFIX}.{n}": d[f"act_scale_{n}"] for n in LET_SITES}
+    runs = {}
+    for aug in (False, True):
+        q = build(d)
+        cfg = dataclasses.replace(config(m), aug_loss=aug, epochs=1)
+        x = d["inps"].clone().to(DEV)
+        runs[aug] = calibrate_layer(q, x, d["inps"].clone().to(DEV), d["mask"].to(DEV), cfg, act_scales, {}, PREFIX, is_llama=True)
+    assert abs(runs[True]["losses"][0] - 2 * runs[False]["losses"][0]) <= 1e-6 * runs[False]["losses"][0]
+    # resume: zero epochs of training starting from the first run's parameters reproduces them
+    q = build(d)
+    cfg = dataclasses.replace(config(m), epochs=1, let_lr=0.0, lwc_lr=0.0)
+    state = {k: v.float() for k, v in runs[False]["omni_state"].items()}
+    res = calibrate_layer(q, d["inps"].clone().to(DEV), d["inps"].clone().to(DEV), d["mask"].to(DEV), cfg, act_scales, {},
+                          PREFIX, is_llama=True, resume_state=state)
+    for k, v in res["omni_state"].items():
+        assert torch.equal(v.cpu(), runs[False]["omni_state"][k].cpu()), k
