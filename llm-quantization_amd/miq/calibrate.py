@@ -415,3 +415,37 @@ def save_omni_parameters(omni_parameters: dict, output_dir: str):
 
 def load_omni_parameters(path: str):
     return torch.load(path, weights_only=True)
+
+
+def calibrate_blocks(qlayers, inps, attention_mask, cfg: CalibConfig, act_scales=None, act_shifts=None,
+                     layer_prefix: str = "model.decoder.layers", dims=None, dp: Optional[DPContext] = None, position_ids=None,
+                     logger=None, is_llama=False, output_dir: Optional[str] = None, resume: Optional[dict] = None,
+                     offload=None):
+    """The layer loop of the reference's ``omniquant()`` (omniquant.py:366-605) over already constructed
+    quantized blocks: every block is calibrated against the full-precision stream, both activation
+    streams are advanced (the quantized one by the calibrated block, the full-precision one by the
+    block with quantization off), and the learned parameters are collected per layer index in the
+    format of ``omni_parameters.pth`` (written after every layer when ``output_dir`` is given, like the
+    reference does, so an interrupted run can be resumed with ``resume=load_omni_parameters(path)``).
+
+    ``inps``: [n_local, T, H] inputs of the first block held by THIS rank.  ``offload``: optional
+    callable(block) invoked after a block is done (e.g. ``lambda b: b.to("cpu")``).
+    Returns (omni_parameters dict, per-layer result list, final quantized-stream activations).
+    """
+    quant_inps = inps
+    fp_inps = inps.clone()
+    omni_parameters = dict(resume) if resume else {}
+    results = []
+    for i, qlayer in enumerate(qlayers):
+        if logger is not None:
+            logger.info(f"=== Start quantize layer {i} ===")
+        res = calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg, act_scales, act_shifts, f"{layer_prefix}.{i}",
+                              dims=dims, dp=dp, position_ids=position_ids, logger=logger, is_llama=is_llama,
+                              resume_state=(resume or {}).get(i))
+        omni_parameters[i] = res["omni_state"]
+        results.append(res)
+        if output_dir is not None and (dp is None or dp.rank == 0):
+            save_omni_parameters(omni_parameters, output_dir)
+        if offload is not None:
+            offload(qlayer)
+    return omni_parameters, results, quant_inps

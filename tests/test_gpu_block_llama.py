@@ -159,3 +159,33 @@ def test_aug_loss_and_resume():
                           PREFIX, is_llama=True, resume_state=state)
     for k, v in res["omni_state"].items():
         assert torch.equal(v.cpu(), runs[False]["omni_state"][k].cpu()), k
+
+
+def test_layer_loop_two_blocks_saves_and_resumes(tmp_path):
+    """calibrate_blocks over two blocks: streams are chained, omni_parameters.pth is written per layer in
+    the reference's format and a resumed run starts from the stored parameters."""
+    import dataclasses
+    from miq.calibrate import calibrate_blocks, load_omni_parameters
+    d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+    m = d["meta"]
+    cfg = dataclasses.replace(config(m), epochs=1)
+    scales = {}
+    for i in range(2):
+        for n in LET_SITES:
+            scales[f"model.layers.{i}.{n}"] = d[f"act_scale_{n}"]
+    blocks = [build(d), build(d)]
+    x0 = d["inps"].clone().to(DEV)
+    params, results, out = calibrate_blocks(blocks, x0, d["mask"].to(DEV), cfg, scales, {}, "model.layers", is_llama=True,
+                                            output_dir=str(tmp_path))
+    assert sorted(params.keys()) == [0, 1] and len(results) == 2 and out.shape == x0.shape
+    assert not torch.equal(out.cpu(), d["inps"])  # the stream moved through both blocks
+    stored = load_omni_parameters(str(tmp_path / "omni_parameters.pth"))
+    assert sorted(stored.keys()) == [0, 1] and list(stored[1].keys()) == d["omni_keys"]
+    for k in d["omni_keys"]:
+        assert stored[0][k].dtype == torch.float16 and torch.equal(stored[0][k].cpu(), params[0][k].cpu())
+    # resume with zero learning rates: layer 0 reproduces the stored parameters
+    cfg0 = dataclasses.replace(cfg, let_lr=0.0, lwc_lr=0.0)
+    p2, _r, _o = calibrate_blocks([build(d)], d["inps"].clone().to(DEV), d["mask"].to(DEV), cfg0, scales, {}, "model.layers",
+                                  is_llama=True, resume={0: {k: v.float() for k, v in stored[0].items()}})
+    for k in d["omni_keys"]:
+        assert torch.equal(p2[0][k].cpu(), stored[0][k].cpu()), k
