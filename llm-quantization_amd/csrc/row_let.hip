@@ -12,10 +12,10 @@
 // fp32 only (the calibration loop keeps LET / LWC parameters and weights in fp32), whole matrix rows
 // as quantization rows (no groups), I a multiple of 4.
 //
-// Work distribution: a team of threads owns one row at a time and strides over the rows, so that
-// every thread keeps its columns: the column vectors cs / shift are loaded once per thread and the
-// column sums of the backward (d_cs, d_shift) are accumulated in registers across the team's rows,
-// written as one partial row per team and folded by a second small kernel (deterministic).
+// Work distribution: forward and the row half of the backward use one team of threads per row (the
+// tiling of the plain row quantizer); the column sums of the backward (d_cs, d_shift) come from a
+// second, column-oriented streaming kernel that rebuilds the element gradients from a small per-row
+// context, followed by a deterministic fold of its row-chunk partials.
 #include "miq_common.h"
 
 namespace miq {
