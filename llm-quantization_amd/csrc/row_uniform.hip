@@ -82,15 +82,11 @@ __device__ __forceinline__ float quant_level(float x, const Divisor<T>& dv, cons
 // the team's next row while computing the current one was measured slower (the second register tile
 // costs more occupancy than the overlap returns), and so was a one-wave-per-row tiling without the
 // block barrier.
+// the work of one team on one quantization row
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out,
-              T* __restrict__ rzp_out, uint8_t* __restrict__ codes) {
-    __shared__ float lds[32];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= geo.n_rows) return;  // whole teams leave together; TEAM > 64 implies RPB == 1
+__device__ __forceinline__ void uniform_fwd_row(const UniArgs<T>& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                                T* __restrict__ out, T* __restrict__ scale_out, T* __restrict__ rzp_out,
+                                                uint8_t* __restrict__ codes) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -129,6 +125,59 @@ k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ sc
     else quantize_row(std::false_type{});
 }
 
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out,
+              T* __restrict__ rzp_out, uint8_t* __restrict__ codes) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;  // whole teams leave together; TEAM > 64 implies RPB == 1
+    uniform_fwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, out, scale_out, rzp_out, codes);
+}
+
+// Several matrices of one row width in ONE launch (the weight matrices of a block are quantized back to
+// back and are independent): a 67 MB matrix alone streams at ~5.0 TB/s because the launch's ramp-up and
+// tail are a sizeable part of its 25 us; 38400 rows in one launch reach 5.7 TB/s.
+constexpr int kMaxBatch = 16;
+template <typename T>
+struct UniBatch {
+    const T* x[kMaxBatch];
+    const T* up[kMaxBatch];
+    const T* low[kMaxBatch];
+    const T* gout[kMaxBatch];   // backward only
+    T* out[kMaxBatch];          // forward: dequantized output; backward: dx (or nullptr)
+    T* a1[kMaxBatch];           // forward: scale; backward: d_up
+    T* a2[kMaxBatch];           // forward: rounded zero point; backward: d_low
+    long long row_start[kMaxBatch + 1];
+    int n;
+};
+
+template <typename T>
+__device__ __forceinline__ int batch_locate(const UniBatch<T>& b, long long row, long long& local) {
+    int m = 0;
+    while (m + 1 < b.n && row >= b.row_start[m + 1]) ++m;
+    local = row - b.row_start[m];
+    return m;
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_uniform_fwd_batch(UniBatch<T> b, UniArgs<T> a, RowGeom geo) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    uniform_fwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.out[m], b.a1[m], b.a2[m], nullptr);
+}
+
 // Backward.  With m = [0 <= round(x/s)+zp <= qmax] and xd = clamp(..) - zp:
 //   dx      = g*m                       (direct path)
 //   dS      = sum_row g*(xd - m*x/s)    (gradient reaching the scale)
@@ -139,16 +188,9 @@ k_uniform_fwd(UniArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ sc
 //   and the row max/min elements of x receive d_xmax*su / d_xmin*sl, split evenly among ties
 //   (zero padding counts as a tie candidate and swallows its share).
 template <typename T, int VEC, int TEAM, int NV, bool WANT_DX>
-// register budget: >= 4 waves per SIMD (two 512-thread blocks per CU) except for the widest fp16 tiles,
-// whose 64 elements per thread would spill under that cap
-__global__ void __launch_bounds__(block_of<TEAM>(), (sizeof(T) == 2 && NV == 8 && TEAM < 1024) ? 2 : 4)
-k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx,
-              T* __restrict__ d_up, T* __restrict__ d_low) {
-    __shared__ float lds[64];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= geo.n_rows) return;
+__device__ __forceinline__ void uniform_bwd_row(const UniArgs<T>& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                                const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
+                                                T* __restrict__ d_low) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -242,6 +284,36 @@ k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restri
     }
 }
 
+template <typename T, int VEC, int TEAM, int NV, bool WANT_DX>
+// register budget: >= 4 waves per SIMD (two 512-thread blocks per CU) except for the widest fp16 tiles,
+// whose 64 elements per thread would spill under that cap
+__global__ void __launch_bounds__(block_of<TEAM>(), (sizeof(T) == 2 && NV == 8 && TEAM < 1024) ? 2 : 4)
+k_uniform_bwd(UniArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx,
+              T* __restrict__ d_up, T* __restrict__ d_low) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    uniform_bwd_row<T, VEC, TEAM, NV, WANT_DX>(a, geo, row, lane, lds, gout, dx, d_up, d_low);
+}
+
+template <typename T, int VEC, int TEAM, int NV, bool WANT_DX>
+__global__ void __launch_bounds__(block_of<TEAM>(), (sizeof(T) == 2 && NV == 8 && TEAM < 1024) ? 2 : 4)
+k_uniform_bwd_batch(UniBatch<T> b, UniArgs<T> a, RowGeom geo) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    uniform_bwd_row<T, VEC, TEAM, NV, WANT_DX>(a, geo, local, lane, lds, b.gout[m], b.out[m], b.a1[m], b.a2[m]);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
@@ -323,6 +395,97 @@ static int launch_uniform(bool backward, const void* gout, const void* x, const 
     return 0;
 }
 
+template <typename T>
+static int launch_uniform_batch(bool backward, int n, const void* const* gout, const void* const* x, const void* const* up,
+                                const void* const* low, void* const* out_or_dx, void* const* a1, void* const* a2,
+                                const int64_t* O, long long I, int n_bits, int symmetric, int flags, hipStream_t stream) {
+    const char* name = backward ? "miq_rowquant_uniform_bwd_batch" : "miq_rowquant_uniform_fwd_batch";
+    if (n == 0 || I == 0) return 0;
+    MIQ_CHECK_ARG(n > 0 && n <= kMaxBatch && x && O && I > 0 && I < (1ll << 31), "%s: 1..%d matrices of one width expected", name, kMaxBatch);
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15, "%s: n_bits=%d outside [2,15]", name, n_bits);
+    MIQ_CHECK_ARG(backward ? (gout && a1 && a2) : (out_or_dx && a1 && a2), "%s: null pointer table", name);
+    constexpr int N = VecOf<T>::N;
+    UniBatch<T> b{};
+    const bool lwc = up != nullptr && up[0] != nullptr;
+    const bool want_dx = backward && out_or_dx != nullptr && out_or_dx[0] != nullptr;
+    bool vec_ok = (I % N == 0);
+    long long rows = 0;
+    b.n = 0;
+    for (int i = 0; i < n; ++i) {
+        MIQ_CHECK_ARG(O[i] >= 0, "%s: negative row count", name);
+        if (O[i] == 0) continue;
+        const int m = b.n++;
+        b.x[m] = (const T*)x[i];
+        b.up[m] = lwc ? (const T*)up[i] : nullptr;
+        b.low[m] = lwc ? (const T*)low[i] : nullptr;
+        b.gout[m] = backward ? (const T*)gout[i] : nullptr;
+        b.out[m] = (backward && !want_dx) ? nullptr : (T*)out_or_dx[i];
+        b.a1[m] = (backward && !lwc) ? nullptr : (T*)a1[i];
+        b.a2[m] = (backward && !lwc) ? nullptr : (T*)a2[i];
+        MIQ_CHECK_ARG(b.x[m] && (!lwc || (b.up[m] && b.low[m])) && (!backward || b.gout[m]) && (backward || (b.out[m] && b.a1[m] && b.a2[m])) &&
+                          (!want_dx || b.out[m]) && (!(backward && lwc) || (b.a1[m] && b.a2[m])),
+                      "%s: null pointer in entry %d (LWC and dx must be given for all matrices or for none)", name, i);
+        vec_ok = vec_ok && aligned16(b.x[m]) && aligned16(b.out[m]) && aligned16(b.gout[m]);
+        b.row_start[m] = rows;
+        rows += O[i];
+    }
+    if (b.n == 0) return 0;
+    for (int m = b.n; m <= kMaxBatch; ++m) b.row_start[m] = rows;
+    RowGeom geo;
+    geo.I = (int)I;
+    geo.g = (int)I;
+    geo.G = 1;
+    geo.n_rows = rows;
+    UniArgs<T> a{};
+    a.row_bits = nullptr;
+    a.n_bits = n_bits;
+    a.symmetric = symmetric;
+    a.clamp_asym = flags & 1;
+    a.preact = (flags >> 1) & 1;
+    const int npack = vec_ok ? geo.g / N : geo.g;
+    MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register-tile capacity", name, geo.g);
+#define LAUNCH_FWD(VECN, TEAM, NV)                                                                                  \
+    {                                                                                                               \
+        constexpr int B = block_of<TEAM>();                                                                         \
+        const long long nb = (rows + (B / TEAM) - 1) / (B / TEAM);                                                  \
+        hipLaunchKernelGGL((k_uniform_fwd_batch<T, VECN, TEAM, NV>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo); \
+    }
+#define LAUNCH_BWD(VECN, TEAM, NV)                                                                                  \
+    {                                                                                                               \
+        constexpr int B = block_of<TEAM>();                                                                         \
+        const long long nb = (rows + (B / TEAM) - 1) / (B / TEAM);                                                  \
+        if (want_dx)                                                                                                \
+            hipLaunchKernelGGL((k_uniform_bwd_batch<T, VECN, TEAM, NV, true>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_uniform_bwd_batch<T, VECN, TEAM, NV, false>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo); \
+    }
+    if (!backward) {
+        if (vec_ok) {
+#define L(TEAM, NV) LAUNCH_FWD(N, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        } else {
+#define L(TEAM, NV) LAUNCH_FWD(1, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        }
+    } else {
+        if (vec_ok) {
+#define L(TEAM, NV) LAUNCH_BWD(N, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        } else {
+#define L(TEAM, NV) LAUNCH_BWD(1, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        }
+    }
+#undef LAUNCH_FWD
+#undef LAUNCH_BWD
+    MIQ_CHECK_LAUNCH(name);
+    return 0;
+}
+
 }  // namespace miq
 
 extern "C" int miq_rowquant_uniform_fwd(const void* x, const void* up, const void* low, const float* row_bits,
@@ -343,6 +506,7 @@ extern "C" int miq_rowquant_uniform_bwd(const void* grad_out, const void* x, con
                                         const float* row_bits, void* dx, void* d_up, void* d_low,
                                         int64_t O, int64_t I, int64_t group, int n_bits, int symmetric,
                                         int flags, int dtype, void* stream) {
+    if (O == 0 || I == 0) return 0;
     MIQ_CHECK_ARG(grad_out, "miq_rowquant_uniform_bwd: null grad_out");
     MIQ_CHECK_ARG(!up || (d_up && d_low), "miq_rowquant_uniform_bwd: d_up/d_low required when up/low are given");
     if (dtype == MIQ_F32)
@@ -352,5 +516,33 @@ extern "C" int miq_rowquant_uniform_bwd(const void* grad_out, const void* x, con
         return miq::launch_uniform<__half>(true, grad_out, x, up, low, row_bits, dx, d_up, d_low, nullptr,
                                            O, I, group, n_bits, symmetric, flags, (hipStream_t)stream);
     miq_set_error("miq_rowquant_uniform_bwd: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_rowquant_uniform_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                                              void* const* out, void* const* scale_out, void* const* rzp_out,
+                                              const int64_t* O, int64_t I, int n_bits, int symmetric, int flags, int dtype,
+                                              void* stream) {
+    if (dtype == MIQ_F32)
+        return miq::launch_uniform_batch<float>(false, n, nullptr, x, up, low, out, scale_out, rzp_out, O, I, n_bits, symmetric,
+                                                flags, (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return miq::launch_uniform_batch<__half>(false, n, nullptr, x, up, low, out, scale_out, rzp_out, O, I, n_bits, symmetric,
+                                                 flags, (hipStream_t)stream);
+    miq_set_error("miq_rowquant_uniform_fwd_batch: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_rowquant_uniform_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                              const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
+                                              const int64_t* O, int64_t I, int n_bits, int symmetric, int flags, int dtype,
+                                              void* stream) {
+    if (dtype == MIQ_F32)
+        return miq::launch_uniform_batch<float>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, symmetric, flags,
+                                                (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return miq::launch_uniform_batch<__half>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, symmetric, flags,
+                                                 (hipStream_t)stream);
+    miq_set_error("miq_rowquant_uniform_bwd_batch: unsupported dtype %d", dtype);
     return -22;
 }

@@ -74,6 +74,93 @@ def rowquant_uniform_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low
     return dx, d_up, d_low
 
 
+def _ptr_table(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def rowquant_uniform_fwd_batch(xs, n_bits: int, symmetric: bool, ups=None, lows=None, preactivated: bool = False):
+    """Row-wise uniform fake quantization of several [O_i, I] matrices of one width and dtype in one launch.
+    Returns (outs, scales, rzps) lists."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*xs, *(ups or []), *(lows or []))
+    I = xs[0].shape[1]
+    for x in xs:
+        if x.dim() != 2 or x.shape[1] != I or x.dtype != xs[0].dtype or not x.is_contiguous():
+            raise L.MiqError("batched row quantization needs contiguous 2-D matrices of one width and dtype")
+    if len(xs) > 16:
+        raise L.MiqError("at most 16 matrices per batch")
+    outs = [torch.empty_like(x) for x in xs]
+    scales = [torch.empty((x.shape[0], 1), dtype=x.dtype, device=dev) for x in xs]
+    rzps = [torch.empty_like(s) for s in scales]
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_uniform_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(outs), _ptr_table(scales), _ptr_table(rzps), O, L.i64(I),
+               L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(xs[0])),
+               L.stream_of(xs[0]))
+    return outs, scales, rzps
+
+
+def rowquant_uniform_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, lows=None, want_dx: bool = True,
+                               preactivated: bool = False):
+    """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None) lists."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*gs, *xs, *(ups or []), *(lows or []))
+    I = xs[0].shape[1]
+    dxs = [torch.empty_like(x) for x in xs] if want_dx else None
+    d_ups = [torch.empty_like(u) for u in ups] if lwc else None
+    d_lows = [torch.empty_like(u) for u in lows] if lwc else None
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    none = [None] * len(xs)
+    with torch.cuda.device(dev):
+        L.call("miq_rowquant_uniform_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(dxs) if want_dx else None, _ptr_table(d_ups if lwc else none),
+               _ptr_table(d_lows if lwc else none), O, L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
+               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+    return dxs, d_ups, d_lows
+
+
+class UniformRowFQBatch(torch.autograd.Function):
+    """apply(n_bits, symmetric, lwc, x_0, [up_0, low_0,] x_1, ...) -> (out_0, scale_0, rzp_0, out_1, ...):
+    several weight matrices of one width through one forward and one backward launch."""
+
+    @staticmethod
+    def forward(ctx, n_bits, symmetric, lwc, *ts):
+        step = 3 if lwc else 1
+        xs = [t.contiguous() for t in ts[0::step]]
+        ups = list(ts[1::step]) if lwc else None
+        lows = list(ts[2::step]) if lwc else None
+        outs, scales, rzps = rowquant_uniform_fwd_batch(xs, n_bits, symmetric, ups, lows)
+        ctx.cfg = (n_bits, symmetric, lwc, len(xs))
+        ctx.save_for_backward(*xs, *(ups or []), *(lows or []))
+        ret = []
+        for o, s, z in zip(outs, scales, rzps):
+            ret += [o, s, z]
+        ctx.mark_non_differentiable(*scales, *rzps)
+        return tuple(ret)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n_bits, symmetric, lwc, n = ctx.cfg
+        saved = ctx.saved_tensors
+        xs = list(saved[:n])
+        ups = list(saved[n:2 * n]) if lwc else None
+        lows = list(saved[2 * n:3 * n]) if lwc else None
+        gs = [(g if g is not None else torch.zeros_like(x)).contiguous() for g, x in zip(grads[0::3], xs)]
+        step = 3 if lwc else 1
+        need_dx = any(ctx.needs_input_grad[3 + i * step] for i in range(n))
+        dxs, d_ups, d_lows = rowquant_uniform_bwd_batch(gs, xs, n_bits, symmetric, ups, lows, want_dx=need_dx)
+        out = [None, None, None]
+        for i in range(n):
+            out.append(dxs[i] if need_dx else None)
+            if lwc:
+                out += [d_ups[i], d_lows[i]]
+        return tuple(out)
+
+
 class UniformRowFQ(torch.autograd.Function):
     """out, scale, rzp = fq(x, up, low); gradients for x, up, low."""
 

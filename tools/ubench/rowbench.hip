@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(256) k_rows(const float* __restrict__ in, floa
     }
 }
 
-int main() {
-    const int O = 4096, I = 4096, NBUF = 6;
+int main(int argc, char** argv) {
+    const int O = argc > 1 ? atoi(argv[1]) : 4096, I = 4096, NBUF = argc > 2 ? atoi(argv[2]) : 6;
     const long long n = (long long)O * I;
     std::vector<float*> in(NBUF), out(NBUF);
     for (int b = 0; b < NBUF; ++b) { CK(hipMalloc(&in[b], n * 4)); CK(hipMalloc(&out[b], n * 4)); }
