@@ -132,11 +132,13 @@ int miq_colquant_fwd(const void* x, const void* scale, const void* rzp, void* ou
  * mode) and dx = grad_out * [level inside the grid].  Otherwise the scale gradient is summed per
  * cluster and routed to the extreme elements: chan_min/chan_max are the per-channel statistics
  * (row `nchunk` of miq_cluster_scale's partial buffers), kmin/kmax the merged [C] statistics,
- * workspace has (3*nchunk + 2)*C floats with nchunk = miq_colstat_chunks(R, C, dtype).
+ * workspace has (3*nchunk + 5)*C floats with nchunk = miq_colstat_chunks(R, C, dtype).
+ * x and grad_out are read once (dx receives the direct path in the same pass); the routed shares
+ * are then added in place to the few elements that attain a cluster extreme.
  * phase 0 runs everything.  Data-parallel callers that quantize with GLOBAL-batch statistics split
- * the call: phase 1 leaves the per-channel sums [dS, #max, #min] in workspace[0:C], [nchunk*C : +C],
- * [2*nchunk*C : +C] (to be summed over ranks by the caller), phase 2 derives the shares from them and
- * writes dx.
+ * the call: phase 1 writes the direct path into dx and leaves the per-channel sums [dS, #max, #min]
+ * in workspace[3*nchunk*C : (3*nchunk + 3)*C] (to be summed over ranks by the caller), phase 2
+ * derives the shares from them and corrects dx.
  */
 int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, const void* rzp,
                      const float* chan_min, const float* chan_max, const void* kmin, const void* kmax,

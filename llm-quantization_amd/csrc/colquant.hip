@@ -260,7 +260,7 @@ k_gather(const T* __restrict__ x, const int* __restrict__ idx, T* __restrict__ o
     const long long total = (long long)nr * npack;
     const T* src = x + r0 * C;  // the nr rows are contiguous in memory
     for (long long i = threadIdx.x; i < total; i += 256)
-        st_pack<T, VEC>(tile + i * VEC, ld_pack<T, VEC>(src + i * VEC));
+        st_pack<T, VEC>(tile + i * VEC, ld_pack_nt<T, VEC>(src + i * VEC));
     __syncthreads();
     T* dst = out + r0 * C;
     for (int p = threadIdx.x; p < npack; p += 256) {

@@ -9,18 +9,32 @@
 //                    autograd splits evenly among tied channels, then evenly among tied rows:
 //                    every element equal to its channel max, in a channel whose max equals the
 //                    cluster max, receives (d_kmax / #tied channels) / #tied rows (same for min).
-// Three kernels: k_colbwd_stats (reads x, g), k_colbwd_shares (tiny), k_colbwd_apply (reads x, g,
-// writes dx).  In eval mode (frozen scales) only the last one runs, without shares.
+// One streaming pass plus a sparse correction:
+//   k_colbwd_stream   reads x and g once, writes the direct path into dx and leaves per (row chunk,
+//                     channel) partial sums of dS and of the number of elements at the channel max / min
+//   k_colbwd_fold     sums the partials over the row chunks (deterministic order)
+//   k_colbwd_shares   per cluster: dS -> the share every routed element receives
+//   k_colbwd_fixup    revisits only the (row chunk, column tile) pairs that hold a routed element and
+//                     adds the share to dx there (typically a few tiles out of ~1000)
+// so the activation and its gradient cross HBM once (3 passes of traffic in total: x, g, dx).
+// In eval mode (frozen scales) a single kernel k_colbwd_apply writes dx = g * m.
 #include "miq_common.h"
 
 namespace miq {
 
-// partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min
+// the direct path of one element: fp32 reproduces autograd's (g*s)/s; for fp16 gradients the plain g is
+// within their rounding
+template <typename T>
+__device__ __forceinline__ float direct_grad(float gv, float s, bool m) {
+    return m ? (sizeof(T) == 4 ? (gv * s) / s : gv) : 0.f;
+}
+
+// dx = direct path; partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ scale,
-               const T* __restrict__ rzp, const float* __restrict__ chan_min, const float* __restrict__ chan_max,
-               float* __restrict__ part, long long R, int C, int rows_per_chunk, float qmax) {
+k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ scale,
+                const T* __restrict__ rzp, const float* __restrict__ chan_min, const float* __restrict__ chan_max,
+                float* __restrict__ part, T* __restrict__ dx, long long R, int C, int rows_per_chunk, float qmax) {
     __shared__ float sm[3][4][64 * VEC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
@@ -42,7 +56,8 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
             cmn[e] = chan_min[col0 + e];
             cmx[e] = chan_max[col0 + e];
         }
-        auto body = [&](const Pack<T, VEC>& a, const Pack<T, VEC>& b) {
+        auto body = [&](const Pack<T, VEC>& a, const Pack<T, VEC>& b, long long r) {
+            Pack<T, VEC> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
@@ -52,7 +67,9 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
                 acc[0][e] += gv * (xd - (m ? q : 0.f));
                 acc[1][e] += (xv == cmx[e]) ? 1.f : 0.f;
                 acc[2][e] += (xv == cmn[e]) ? 1.f : 0.f;
+                o.e[e] = from_f<T>(direct_grad<T>(gv, s[e], m));
             }
+            st_pack<T, VEC>(dx + r * C + col0, o);
         };
         long long r = r0 + w;
         for (; r + 12 < r1; r += 16) {
@@ -60,14 +77,14 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
             Pack<T, VEC> a1 = ld_pack<T, VEC>(x + (r + 4) * C + col0), b1 = ld_pack<T, VEC>(g + (r + 4) * C + col0);
             Pack<T, VEC> a2 = ld_pack<T, VEC>(x + (r + 8) * C + col0), b2 = ld_pack<T, VEC>(g + (r + 8) * C + col0);
             Pack<T, VEC> a3 = ld_pack<T, VEC>(x + (r + 12) * C + col0), b3 = ld_pack<T, VEC>(g + (r + 12) * C + col0);
-            body(a0, b0);
-            body(a1, b1);
-            body(a2, b2);
-            body(a3, b3);
+            body(a0, b0, r);
+            body(a1, b1, r + 4);
+            body(a2, b2, r + 8);
+            body(a3, b3, r + 12);
         }
         for (; r < r1; r += 4) {
             Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
-            body(a0, b0);
+            body(a0, b0, r);
         }
     }
 #pragma unroll
@@ -87,10 +104,10 @@ k_colbwd_stats(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
     }
 }
 
-// fold the row-chunk partials into chunk 0.  Block = 64 channels x 4 waves, wave w sums chunks
-// w, w+4, ...; every block only touches its own 64 columns, so folding in place is race-free once
-// all of the block's reads are done (the barrier).
-__global__ void __launch_bounds__(256) k_colbwd_fold(float* __restrict__ part, int nchunk, int C) {
+// fold the row-chunk partials into sums[3, C] (the per-chunk counts stay: the correction kernel reads
+// them).  Block = 64 channels x 4 waves, wave w sums chunks w, w+4, ...
+__global__ void __launch_bounds__(256)
+k_colbwd_fold(const float* __restrict__ part, float* __restrict__ sums, int nchunk, int C) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -111,13 +128,13 @@ __global__ void __launch_bounds__(256) k_colbwd_fold(float* __restrict__ part, i
     sm[w][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (w == 0 && valid)
-        part[((long long)k * nchunk) * C + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        sums[(long long)k * C + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 // one block per cluster (+1 for un-clustered channels): per-channel shares for the max / min elements
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_colbwd_shares(const float* __restrict__ part, int nchunk, int C, const float* __restrict__ chan_min,
+k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__ chan_min,
                 const float* __restrict__ chan_max, const T* __restrict__ kmin, const T* __restrict__ kmax,
                 const int* __restrict__ starts, int ncl, float qmax, float* __restrict__ share_min,
                 float* __restrict__ share_max) {
@@ -127,7 +144,7 @@ k_colbwd_shares(const float* __restrict__ part, int nchunk, int C, const float* 
     const int st = own ? starts[ncl] : starts[k];
     const int en = own ? C : starts[k + 1];
     const float lo = rnd<T>(kClipLo);
-    auto colsum = [&](int which, int c) { return part[((long long)which * nchunk) * C + c]; };  // folded
+    auto colsum = [&](int which, int c) { return sums[(long long)which * C + c]; };
     if (own) {
         for (int c = st + threadIdx.x; c < en; c += 256) {
             const float mn = to_f<T>(kmin[c]), mx = to_f<T>(kmax[c]);
@@ -158,31 +175,24 @@ k_colbwd_shares(const float* __restrict__ part, int nchunk, int C, const float* 
     }
 }
 
-template <typename T, int VEC, bool ROUTE>
+// eval mode (frozen scales): dx = g * [level inside the grid]
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ scale,
-               const T* __restrict__ rzp, const float* __restrict__ chan_min, const float* __restrict__ chan_max,
-               const float* __restrict__ share_min, const float* __restrict__ share_max, T* __restrict__ dx,
-               long long R, int C, int rows_per_chunk, float qmax) {
+               const T* __restrict__ rzp, T* __restrict__ dx, long long R, int C, int rows_per_chunk, float qmax) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
     if (col0 >= C) return;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
-    float s[VEC], rs[VEC], z[VEC], cmn[VEC], cmx[VEC], hmn[VEC], hmx[VEC];
+    float s[VEC], rs[VEC], z[VEC];
     Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         s[e] = to_f<T>(ps.e[e]);
         rs[e] = 1.0f / s[e];
         z[e] = to_f<T>(pz.e[e]);
-        if (ROUTE) {
-            cmn[e] = chan_min[col0 + e];
-            cmx[e] = chan_max[col0 + e];
-            hmn[e] = share_min[col0 + e];
-            hmx[e] = share_max[col0 + e];
-        }
     }
     auto body = [&](const Pack<T, VEC>& a, const Pack<T, VEC>& b, long long r) {
         Pack<T, VEC> o;
@@ -192,13 +202,7 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
             float q, xd;
             bool m;
             fq_terms<T>(xv, s[e], rs[e], z[e], qmax, q, m, xd);
-            // fp32 reproduces autograd's (g*s)/s; for fp16 gradients the plain g is within their rounding
-            float d = m ? (sizeof(T) == 4 ? (gv * s[e]) / s[e] : gv) : 0.f;
-            if (ROUTE) {
-                if (xv == cmx[e]) d += hmx[e];
-                if (xv == cmn[e]) d += hmn[e];
-            }
-            o.e[e] = from_f<T>(d);
+            o.e[e] = from_f<T>(direct_grad<T>(gv, s[e], m));
         }
         st_pack<T, VEC>(dx + r * C + col0, o);
     };
@@ -219,6 +223,63 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
     }
 }
 
+// sparse correction after k_colbwd_stream: same (column tile, row chunk) grid; a thread goes back over its
+// rows only if one of its channels holds, inside this row chunk, an element equal to the channel max / min
+// (the per-chunk counts of the streaming pass say so) whose share is not zero.  dx += share at those
+// elements: the sum (direct + share_max) + share_min of a single-pass kernel, in the same order.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_colbwd_fixup(const T* __restrict__ x, const float* __restrict__ part, int nchunk,
+               const float* __restrict__ chan_min, const float* __restrict__ chan_max,
+               const float* __restrict__ share_min, const float* __restrict__ share_max, T* __restrict__ dx,
+               long long R, int C, int rows_per_chunk) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    if (col0 >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float cmn[VEC], cmx[VEC], hmn[VEC], hmx[VEC];
+    bool amx[VEC], amn[VEC], any = false;
+    const float* cnt_max = part + ((long long)1 * nchunk + blockIdx.y) * C + col0;
+    const float* cnt_min = part + ((long long)2 * nchunk + blockIdx.y) * C + col0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        hmx[e] = share_max[col0 + e];
+        hmn[e] = share_min[col0 + e];
+        // a NaN share compares unequal to zero and is added, like every other value
+        amx[e] = cnt_max[e] > 0.f && hmx[e] != 0.f;
+        amn[e] = cnt_min[e] > 0.f && hmn[e] != 0.f;
+        any = any || amx[e] || amn[e];
+    }
+    if (!any) return;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        cmx[e] = chan_max[col0 + e];
+        cmn[e] = chan_min[col0 + e];
+    }
+    for (long long r = r0 + w; r < r1; r += 4) {
+        const Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
+        bool hit = false;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xv = to_f<T>(a.e[e]);
+            hit = hit || (amx[e] && xv == cmx[e]) || (amn[e] && xv == cmn[e]);
+        }
+        if (!hit) continue;
+        Pack<T, VEC> o = ld_pack<T, VEC>(dx + r * C + col0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xv = to_f<T>(a.e[e]);
+            float d = to_f<T>(o.e[e]);
+            if (amx[e] && xv == cmx[e]) d += hmx[e];
+            if (amn[e] && xv == cmn[e]) d += hmn[e];
+            o.e[e] = from_f<T>(d);
+        }
+        st_pack<T, VEC>(dx + r * C + col0, o);
+    }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
@@ -231,38 +292,41 @@ static int colquant_bwd_t(const void* g, const void* x, const void* scale, const
     const float qmax = (float)((1 << n_bits) - 1);
     const int tiles = (int)(vec_ok ? (C / N + 63) / 64 : (C + 63) / 64);
     const int rpc = (int)((R + nchunk - 1) / nchunk);
-    const bool route = chan_min != nullptr;
-    float* part = ws;                                    // [3, nchunk, C]
-    float* share_min = ws + 3ll * nchunk * C;            // [C]
-    float* share_max = share_min + C;                    // [C]
-    if (route && phase != 2) {
+    const dim3 grid(tiles, nchunk), block(256);
+    if (!chan_min) {  // eval mode
         if (vec_ok)
-            hipLaunchKernelGGL((k_colbwd_stats<T, N>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
-                               (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
+            hipLaunchKernelGGL((k_colbwd_apply<T, N>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
+                               (const T*)rzp, (T*)dx, R, (int)C, rpc, qmax);
         else
-            hipLaunchKernelGGL((k_colbwd_stats<T, 1>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, (const T*)g,
-                               (const T*)scale, (const T*)rzp, chan_min, chan_max, part, R, (int)C, rpc, qmax);
-        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64), 3), dim3(256), 0, stream, part, nchunk, (int)C);
-    }
-    if (phase == 1) {
+            hipLaunchKernelGGL((k_colbwd_apply<T, 1>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
+                               (const T*)rzp, (T*)dx, R, (int)C, rpc, qmax);
         MIQ_CHECK_LAUNCH("miq_colquant_bwd");
         return 0;
     }
-    if (route) {
-        const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
-        hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(grid), dim3(256), 0, stream, part, nchunk, (int)C, chan_min, chan_max,
+    float* part = ws;                          // [3, nchunk, C]
+    float* sums = ws + 3ll * nchunk * C;       // [3, C]
+    float* share_min = sums + 3ll * C;         // [C]
+    float* share_max = share_min + C;          // [C]
+    if (phase != 2) {
+        if (vec_ok)
+            hipLaunchKernelGGL((k_colbwd_stream<T, N>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
+                               (const T*)rzp, chan_min, chan_max, part, (T*)dx, R, (int)C, rpc, qmax);
+        else
+            hipLaunchKernelGGL((k_colbwd_stream<T, 1>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
+                               (const T*)rzp, chan_min, chan_max, part, (T*)dx, R, (int)C, rpc, qmax);
+        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64), 3), block, 0, stream, part, sums, nchunk, (int)C);
+    }
+    if (phase != 1) {
+        const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
+        hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk), block, 0, stream, sums, (int)C, chan_min, chan_max,
                            (const T*)kmin, (const T*)kmax, starts, ncl, qmax, share_min, share_max);
+        if (vec_ok)
+            hipLaunchKernelGGL((k_colbwd_fixup<T, N>), grid, block, 0, stream, (const T*)x, part, nchunk, chan_min, chan_max,
+                               share_min, share_max, (T*)dx, R, (int)C, rpc);
+        else
+            hipLaunchKernelGGL((k_colbwd_fixup<T, 1>), grid, block, 0, stream, (const T*)x, part, nchunk, chan_min, chan_max,
+                               share_min, share_max, (T*)dx, R, (int)C, rpc);
     }
-#define APPLY(VECN, RT)                                                                                               \
-    hipLaunchKernelGGL((k_colbwd_apply<T, VECN, RT>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x,         \
-                       (const T*)g, (const T*)scale, (const T*)rzp, chan_min, chan_max, share_min, share_max, (T*)dx, \
-                       R, (int)C, rpc, qmax)
-    if (vec_ok) {
-        if (route) APPLY(N, true); else APPLY(N, false);
-    } else {
-        if (route) APPLY(1, true); else APPLY(1, false);
-    }
-#undef APPLY
     MIQ_CHECK_LAUNCH("miq_colquant_bwd");
     return 0;
 }
@@ -276,7 +340,7 @@ extern "C" int miq_colquant_bwd(const void* grad_out, const void* x, const void*
                                 const int* starts, int n_clusters, int64_t covered, float* workspace, int nchunk,
                                 void* dx, int64_t R, int64_t C, int n_bits, int phase, int dtype, void* stream) {
     if (R == 0 || C == 0) return 0;
-    MIQ_CHECK_ARG(grad_out && x && scale && rzp && (dx || phase == 1) && R > 0 && C > 0 && C < (1ll << 31),
+    MIQ_CHECK_ARG(grad_out && x && scale && rzp && dx && R > 0 && C > 0 && C < (1ll << 31),
                   "miq_colquant_bwd: null pointer or bad shape");
     MIQ_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 0 || chan_min), "miq_colquant_bwd: phase %d needs the routing inputs", phase);
     MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && nchunk >= 1, "miq_colquant_bwd: bad n_bits/nchunk");

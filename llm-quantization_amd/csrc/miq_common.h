@@ -48,6 +48,13 @@ template <> struct VecOf<__half> { static constexpr int N = 8; };
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
 
+template <int BYTES> struct RawVec;
+template <> struct RawVec<16> { typedef unsigned int type __attribute__((ext_vector_type(4))); };
+template <> struct RawVec<8> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
+template <> struct RawVec<4> { typedef unsigned int type; };
+template <> struct RawVec<2> { typedef unsigned short type; };
+template <> struct RawVec<1> { typedef unsigned char type; };
+
 template <typename T, int VEC>
 __device__ __forceinline__ Pack<T, VEC> ld_pack(const T* p) {
     return *reinterpret_cast<const Pack<T, VEC>*>(p);
@@ -55,6 +62,19 @@ __device__ __forceinline__ Pack<T, VEC> ld_pack(const T* p) {
 template <typename T, int VEC>
 __device__ __forceinline__ void st_pack(T* p, const Pack<T, VEC>& v) {
     *reinterpret_cast<Pack<T, VEC>*>(p) = v;
+}
+// Non-temporal load for the LAST use of a streamed operand (the weight and the incoming gradient of a
+// weight backward, the source of a gather).  Measured on MI355X: +4 % on the row backward, +12 % on the
+// gather.  Not for operands that a later kernel of the same pass reads again (the activation between its
+// statistics and quantization passes: -5 %), and not for stores: a non-temporal store of an output is
+// 7 % faster in isolation but slows the consumer that would have found the lines in cache.
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> ld_pack_nt(const T* p) {
+    using V = typename RawVec<sizeof(Pack<T, VEC>)>::type;
+    const V r = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    Pack<T, VEC> o;
+    __builtin_memcpy(&o, &r, sizeof(r));
+    return o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,6 +264,15 @@ struct RowTile {
         for (int k = 0; k < NV; ++k) {
             const int j = k * TEAM + t;
             if (j < npack) v[k] = ld_pack<T, VEC>(base + (long long)j * VEC);
+        }
+    }
+    __device__ __forceinline__ void load_nt(const T* base, int len, int lane) {
+        t = lane;
+        npack = len / VEC;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = k * TEAM + t;
+            if (j < npack) v[k] = ld_pack_nt<T, VEC>(base + (long long)j * VEC);
         }
     }
     template <class F> __device__ __forceinline__ void for_each(F f) const {

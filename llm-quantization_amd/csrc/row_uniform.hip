@@ -91,7 +91,7 @@ __device__ __forceinline__ void uniform_fwd_row(const UniArgs<T>& a, const RowGe
     int len;
     row_span(geo, row, base, len);
     RowTile<T, VEC, TEAM, NV> x;
-    x.load(a.x + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const UniCtx c = uniform_ctx<T>(a, row, rmin, rmax);
@@ -195,8 +195,8 @@ __device__ __forceinline__ void uniform_bwd_row(const UniArgs<T>& a, const RowGe
     int len;
     row_span(geo, row, base, len);
     RowTile<T, VEC, TEAM, NV> x, g;
-    x.load(a.x + base, len, lane);
-    g.load(gout + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
+    g.load_nt(gout + base, len, lane);
     const bool padded = len < geo.g;
     float rmin, rmax;
     row_minmax(x, padded, lds, rmin, rmax);

@@ -12,7 +12,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiq.so")
+LIB_PATH = os.environ.get("MIQ_LIB") or os.path.join(_HERE, "libmiq.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "miq.h"))
 
 F32, F16 = 0, 1

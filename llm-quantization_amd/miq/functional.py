@@ -334,7 +334,7 @@ def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
     nchunk = colstat_chunks(R, C, x2d.dtype)
     if route is not None:
         chan_min, chan_max, kmin, kmax, layout = route
-        ws = torch.empty((3 * nchunk + 2) * C, dtype=torch.float32, device=dev)
+        ws = torch.empty((3 * nchunk + 5) * C, dtype=torch.float32, device=dev)
         args = (L.ptr(chan_min), L.ptr(chan_max), L.ptr(kmin), L.ptr(kmax), L.ptr(layout.starts),
                 L.i32(layout.n_clusters), L.i64(layout.covered), L.ptr(ws))
     else:
@@ -345,9 +345,7 @@ def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
         if route is not None and dp is not None and dp.active and dp.sync_stats:
             import torch.distributed as tdist
             L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(1), code, st)
-            sums = ws[:3 * nchunk * C].view(3, nchunk, C)[:, 0, :].contiguous()
-            tdist.all_reduce(sums, group=dp.group)
-            ws[:3 * nchunk * C].view(3, nchunk, C)[:, 0, :].copy_(sums)
+            tdist.all_reduce(ws[3 * nchunk * C:(3 * nchunk + 3) * C], group=dp.group)  # [dS, #max, #min] per channel
             L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(2), code, st)
         else:
             L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(0), code, st)

@@ -36,10 +36,10 @@ CASES = [
 
 
 def _phased_bwd(g, x, st, bits, layout):
-    """miq_colquant_bwd as phase 1 (sums + fold) then phase 2 (shares + apply)."""
+    """miq_colquant_bwd as phase 1 (stream + fold) then phase 2 (shares + correction)."""
     R, C = x.shape
     nchunk = F.colstat_chunks(R, C, x.dtype)
-    ws = torch.empty((3 * nchunk + 2) * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty((3 * nchunk + 5) * C, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     for phase in (1, 2):
         L.call("miq_colquant_bwd", L.ptr(g), L.ptr(x), L.ptr(st["scale"]), L.ptr(st["rzp"]), L.ptr(st["chan_min"]),
