@@ -18,20 +18,39 @@
 //                     adds the share to dx there (typically a few tiles out of ~1000)
 // so the activation and its gradient cross HBM once (3 passes of traffic in total: x, g, dx).
 // In eval mode (frozen scales) a single kernel k_colbwd_apply writes dx = g * m.
+#include <type_traits>
 #include "miq_common.h"
 
 namespace miq {
 
-// the direct path of one element: fp32 reproduces autograd's (g*s)/s; for fp16 gradients the plain g is
-// within their rounding
-template <typename T>
-__device__ __forceinline__ float direct_grad(float gv, float s, bool m) {
-    return m ? (sizeof(T) == 4 ? (gv * s) / s : gv) : 0.f;
+// Quotient x/s of the backward pass.  fp16: the correctly rounded fp16 quotient (col_div).  fp32: reciprocal
+// multiply plus one FMA correction step, within one ulp of (and almost always equal to) the IEEE quotient at
+// a third of its instructions; the backward only sums it and takes round(q), so the forward's bit-exact
+// division is not needed here.
+template <typename T> __device__ __forceinline__ float bwd_div(float x, float s, float rs);
+template <> __device__ __forceinline__ float bwd_div<__half>(float x, float s, float rs) { return col_div<__half>(x, s, rs); }
+template <> __device__ __forceinline__ float bwd_div<float>(float x, float s, float rs) {
+    const float q0 = x * rs;
+    return __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
 }
 
-// dx = direct path; partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min
+// the direct path of one element: fp32 follows autograd's (g*s)/s; for fp16 gradients the plain g is within
+// their rounding (and is passed through without conversion)
+template <typename T> __device__ __forceinline__ T direct_out(T graw, float gv, float s, float rs, bool m);
+template <> __device__ __forceinline__ float direct_out<float>(float, float gv, float s, float rs, bool m) {
+    return m ? bwd_div<float>(gv * s, s, rs) : 0.f;
+}
+template <> __device__ __forceinline__ __half direct_out<__half>(__half graw, float, float, float, bool m) {
+    return m ? graw : __ushort_as_half((unsigned short)0);
+}
+
+// dx = direct path; partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min.
+// The per-element arithmetic is what bounds this kernel for fp16 (6 bytes per element), so it is kept short:
+// tie counts are integer adds of the compare result, the clamp is a median-of-three (a NaN level, which
+// only +-inf inputs produce, is carried into the sum through the masked quotient instead), and the fp16
+// re-roundings of integer intermediates are skipped when every level is exactly representable.
 template <typename T, int VEC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)  // four waves per SIMD: all four blocks of a CU resident
 k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ scale,
                 const T* __restrict__ rzp, const float* __restrict__ chan_min, const float* __restrict__ chan_max,
                 float* __restrict__ part, T* __restrict__ dx, long long R, int C, int rows_per_chunk, float qmax) {
@@ -42,11 +61,33 @@ k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __res
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
-    float acc[3][VEC];
+    float acc[VEC];
+    int nmx[VEC], nmn[VEC];
+    float s[VEC], rs[VEC], z[VEC], cmn[VEC], cmx[VEC];
+    bool ok = true;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = acc[2][e] = 0.f;
+    for (int e = 0; e < VEC; ++e) {
+        acc[e] = 0.f;
+        nmx[e] = nmn[e] = 0;
+    }
+    // A wave owns rows r0 + w, r0 + w + 4, ...; it handles them UNR at a time with all 2*UNR loads in
+    // flight (a chunk is typically 32 rows: one or two batches per wave).  The first batch is issued before the per-channel parameters are fetched.
+    // 32 elements per batch keep the kernel under 128 registers (four waves per SIMD) without spills; larger
+    // batches were measured: no faster in fp32, slower in fp16
+    constexpr int UNR = VEC == 8 ? 2 : 4;
+    Pack<T, VEC> a[UNR], b[UNR];
+    auto load_batch = [&](long long r) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long rr = r + 4 * u;
+            if (rr < r1) {
+                a[u] = ld_pack<T, VEC>(x + rr * C + col0);
+                b[u] = ld_pack<T, VEC>(g + rr * C + col0);
+            }
+        }
+    };
     if (valid) {
-        float s[VEC], rs[VEC], z[VEC], cmn[VEC], cmx[VEC];
+        load_batch(r0 + w);
         Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -55,42 +96,52 @@ k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __res
             z[e] = to_f<T>(pz.e[e]);
             cmn[e] = chan_min[col0 + e];
             cmx[e] = chan_max[col0 + e];
+            ok = ok && ints_exact<T>(z[e], qmax);
         }
-        auto body = [&](const Pack<T, VEC>& a, const Pack<T, VEC>& b, long long r) {
+    }
+    const bool exact_int = __all(ok);  // wave-uniform
+    auto stream_rows = [&](auto exact_tag) {
+        constexpr bool EX = decltype(exact_tag)::value;
+        auto body = [&](const Pack<T, VEC>& pa, const Pack<T, VEC>& pb, long long r) {
             Pack<T, VEC> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
-                float q, xd;
-                bool m;
-                fq_terms<T>(xv, s[e], rs[e], z[e], qmax, q, m, xd);
-                acc[0][e] += gv * (xd - (m ? q : 0.f));
-                acc[1][e] += (xv == cmx[e]) ? 1.f : 0.f;
-                acc[2][e] += (xv == cmn[e]) ? 1.f : 0.f;
-                o.e[e] = from_f<T>(direct_grad<T>(gv, s[e], m));
+                const float xv = to_f<T>(pa.e[e]), gv = to_f<T>(pb.e[e]);
+                const float q = bwd_div<T>(xv, s[e], rs[e]);
+                const float rq = rint_ste(q);
+                float xi = rq + z[e];
+                if (!EX) xi = rnd<T>(xi);
+                const bool m = (xi >= 0.f) && (xi <= qmax);
+                float xd = __builtin_amdgcn_fmed3f(xi, 0.f, qmax) - z[e];
+                if (!EX) xd = rnd<T>(xd);
+                // outside the grid the quotient drops out; rq - rq is 0, or NaN when the level is NaN
+                acc[e] += gv * (xd - (m ? q : rq - rq));
+                nmx[e] += (xv == cmx[e]) ? 1 : 0;
+                nmn[e] += (xv == cmn[e]) ? 1 : 0;
+                o.e[e] = direct_out<T>(pb.e[e], gv, s[e], rs[e], m);
             }
             st_pack<T, VEC>(dx + r * C + col0, o);
         };
-        long long r = r0 + w;
-        for (; r + 12 < r1; r += 16) {
-            Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
-            Pack<T, VEC> a1 = ld_pack<T, VEC>(x + (r + 4) * C + col0), b1 = ld_pack<T, VEC>(g + (r + 4) * C + col0);
-            Pack<T, VEC> a2 = ld_pack<T, VEC>(x + (r + 8) * C + col0), b2 = ld_pack<T, VEC>(g + (r + 8) * C + col0);
-            Pack<T, VEC> a3 = ld_pack<T, VEC>(x + (r + 12) * C + col0), b3 = ld_pack<T, VEC>(g + (r + 12) * C + col0);
-            body(a0, b0, r);
-            body(a1, b1, r + 4);
-            body(a2, b2, r + 8);
-            body(a3, b3, r + 12);
+        // (a separate unguarded copy of the batch for the interior of the chunk doubles the code and, with
+        // it, the register pressure: measured 2x slower)
+        for (long long r = r0 + w; r < r1;) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (r + 4 * u < r1) body(a[u], b[u], r + 4 * u);
+            r += 4 * UNR;
+            if (r < r1) load_batch(r);
         }
-        for (; r < r1; r += 4) {
-            Pack<T, VEC> a0 = ld_pack<T, VEC>(x + r * C + col0), b0 = ld_pack<T, VEC>(g + r * C + col0);
-            body(a0, b0, r);
-        }
+    };
+    if (valid) {
+        if (sizeof(T) == 4 || exact_int) stream_rows(std::true_type{});
+        else stream_rows(std::false_type{});
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) sm[k][w][lane * VEC + e] = acc[k][e];
+    for (int e = 0; e < VEC; ++e) {
+        sm[0][w][lane * VEC + e] = acc[e];
+        sm[1][w][lane * VEC + e] = (float)nmx[e];
+        sm[2][w][lane * VEC + e] = (float)nmn[e];
+    }
     __syncthreads();
     if (w == 0 && valid) {
 #pragma unroll
@@ -113,19 +164,22 @@ k_colbwd_fold(const float* __restrict__ part, float* __restrict__ sums, int nchu
     const int c = blockIdx.x * 64 + lane;
     const int k = blockIdx.y;  // plane: dS, #max, #min
     const bool valid = c < C;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    float acc = 0.f;
     if (valid) {
         const float* p = part + ((long long)k * nchunk) * C + c;
-        int j = w;
-        for (; j + 12 < nchunk; j += 16) {
-            v0 += p[(long long)j * C];
-            v1 += p[(long long)(j + 4) * C];
-            v2 += p[(long long)(j + 8) * C];
-            v3 += p[(long long)(j + 12) * C];
+        // wave w sums chunks w, w+4, ... in this fixed order; up to 16 loads in flight per thread
+        for (int j0 = w; j0 < nchunk; j0 += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = j0 + 4 * u;
+                v[u] = j < nchunk ? p[(long long)j * C] : 0.f;
+            }
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+                   (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
         }
-        for (; j < nchunk; j += 4) v0 += p[(long long)j * C];
     }
-    sm[w][lane] = (v0 + v1) + (v2 + v3);
+    sm[w][lane] = acc;
     __syncthreads();
     if (w == 0 && valid)
         sums[(long long)k * C + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
@@ -156,20 +210,35 @@ k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__
         }
         return;
     }
-    // cluster totals: dS, number of channels attaining the cluster max / min
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int c = st + threadIdx.x; c < en; c += 256) {
+    if (en <= st) return;
+    const float mn = to_f<T>(kmin[st]), mx = to_f<T>(kmax[st]);  // constant over the cluster
+    // cluster totals: dS, number of channels attaining the cluster max / min.  Each thread keeps its first
+    // channel in registers, so clusters of up to 256 channels need a single round of loads.
+    const int c0 = st + threadIdx.x;
+    const bool has0 = c0 < en;
+    float ds0 = 0.f, nmx0 = 1.f, nmn0 = 1.f, cx0 = 0.f, cn0 = 0.f;
+    if (has0) {
+        ds0 = colsum(0, c0);
+        nmx0 = colsum(1, c0);
+        nmn0 = colsum(2, c0);
+        cx0 = chan_max[c0];
+        cn0 = chan_min[c0];
+    }
+    float acc[3] = {ds0, (has0 && cx0 == mx) ? 1.f : 0.f, (has0 && cn0 == mn) ? 1.f : 0.f};
+    for (int c = c0 + 256; c < en; c += 256) {
         acc[0] += colsum(0, c);
-        acc[1] += (chan_max[c] == to_f<T>(kmax[c])) ? 1.f : 0.f;
-        acc[2] += (chan_min[c] == to_f<T>(kmin[c])) ? 1.f : 0.f;
+        acc[1] += (chan_max[c] == mx) ? 1.f : 0.f;
+        acc[2] += (chan_min[c] == mn) ? 1.f : 0.f;
     }
     team_sum<256, 3>(acc, lds);
-    if (en <= st) return;
-    const float mn = to_f<T>(kmin[st]), mx = to_f<T>(kmax[st]);
     const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
     const bool live = s_raw >= lo && s_raw <= kClipHi;
     const float d = live ? acc[0] / qmax : 0.f;
-    for (int c = st + threadIdx.x; c < en; c += 256) {
+    if (has0) {
+        share_max[c0] = (cx0 == mx) ? (d / acc[1]) / nmx0 : 0.f;
+        share_min[c0] = (cn0 == mn) ? (-d / acc[2]) / nmn0 : 0.f;
+    }
+    for (int c = c0 + 256; c < en; c += 256) {
         share_max[c] = (chan_max[c] == mx) ? (d / acc[1]) / colsum(1, c) : 0.f;
         share_min[c] = (chan_min[c] == mn) ? (-d / acc[2]) / colsum(2, c) : 0.f;
     }
@@ -199,10 +268,9 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
-            float q, xd;
-            bool m;
-            fq_terms<T>(xv, s[e], rs[e], z[e], qmax, q, m, xd);
-            o.e[e] = from_f<T>(direct_grad<T>(gv, s[e], m));
+            const float xi = rnd<T>(rint_ste(bwd_div<T>(xv, s[e], rs[e])) + z[e]);
+            const bool m = (xi >= 0.f) && (xi <= qmax);
+            o.e[e] = direct_out<T>(b.e[e], gv, s[e], rs[e], m);
         }
         st_pack<T, VEC>(dx + r * C + col0, o);
     };
@@ -223,10 +291,29 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
     }
 }
 
-// sparse correction after k_colbwd_stream: same (column tile, row chunk) grid; a thread goes back over its
-// rows only if one of its channels holds, inside this row chunk, an element equal to the channel max / min
-// (the per-chunk counts of the streaming pass say so) whose share is not zero.  dx += share at those
-// elements: the sum (direct + share_max) + share_min of a single-pass kernel, in the same order.
+// VEC consecutive floats, as 16-byte loads when VEC is a multiple of 4 (p 16-byte aligned then)
+template <int VEC>
+__device__ __forceinline__ void ld_floats(const float* __restrict__ p, float* out) {
+    if constexpr (VEC % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const Pack<float, 4> v = ld_pack<float, 4>(p + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[4 * q + e] = v.e[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[e] = p[e];
+    }
+}
+
+// sparse correction after k_colbwd_stream: same (column tile, row chunk) grid, a lane owns one pack of
+// channels, wave w every 4th row of the chunk.  A lane goes back over its rows only if one of its channels
+// holds, inside this chunk, an element equal to the channel max / min (the per-chunk counts of the
+// streaming pass say so) whose share is not zero.  dx += share at those elements: the sum
+// (direct + share_max) + share_min of a single-pass kernel, in the same order.  Usually a handful of lanes
+// do any work (their loads are issued eight rows at a time: the kernel is latency-bound); with ReLU-style
+// mass ties every block streams its tile with coalesced 16-byte accesses.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 k_colbwd_fixup(const T* __restrict__ x, const float* __restrict__ part, int nchunk,
@@ -239,34 +326,30 @@ k_colbwd_fixup(const T* __restrict__ x, const float* __restrict__ part, int nchu
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
-    float cmn[VEC], cmx[VEC], hmn[VEC], hmx[VEC];
+    float hmn[VEC], hmx[VEC], nmx[VEC], nmn[VEC], cmn[VEC], cmx[VEC];
+    ld_floats<VEC>(part + ((long long)1 * nchunk + blockIdx.y) * C + col0, nmx);
+    ld_floats<VEC>(part + ((long long)2 * nchunk + blockIdx.y) * C + col0, nmn);
+    ld_floats<VEC>(share_max + col0, hmx);
+    ld_floats<VEC>(share_min + col0, hmn);
+    ld_floats<VEC>(chan_max + col0, cmx);
+    ld_floats<VEC>(chan_min + col0, cmn);
     bool amx[VEC], amn[VEC], any = false;
-    const float* cnt_max = part + ((long long)1 * nchunk + blockIdx.y) * C + col0;
-    const float* cnt_min = part + ((long long)2 * nchunk + blockIdx.y) * C + col0;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        hmx[e] = share_max[col0 + e];
-        hmn[e] = share_min[col0 + e];
         // a NaN share compares unequal to zero and is added, like every other value
-        amx[e] = cnt_max[e] > 0.f && hmx[e] != 0.f;
-        amn[e] = cnt_min[e] > 0.f && hmn[e] != 0.f;
+        amx[e] = nmx[e] > 0.f && hmx[e] != 0.f;
+        amn[e] = nmn[e] > 0.f && hmn[e] != 0.f;
         any = any || amx[e] || amn[e];
     }
     if (!any) return;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        cmx[e] = chan_max[col0 + e];
-        cmn[e] = chan_min[col0 + e];
-    }
-    for (long long r = r0 + w; r < r1; r += 4) {
-        const Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
+    auto fix = [&](const Pack<T, VEC>& a, long long r) {
         bool hit = false;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float xv = to_f<T>(a.e[e]);
             hit = hit || (amx[e] && xv == cmx[e]) || (amn[e] && xv == cmn[e]);
         }
-        if (!hit) continue;
+        if (!hit) return;
         Pack<T, VEC> o = ld_pack<T, VEC>(dx + r * C + col0);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -277,7 +360,16 @@ k_colbwd_fixup(const T* __restrict__ x, const float* __restrict__ part, int nchu
             o.e[e] = from_f<T>(d);
         }
         st_pack<T, VEC>(dx + r * C + col0, o);
+    };
+    long long r = r0 + w;
+    for (; r + 28 < r1; r += 32) {
+        Pack<T, VEC> a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = ld_pack<T, VEC>(x + (r + 4 * u) * C + col0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fix(a[u], r + 4 * u);
     }
+    for (; r < r1; r += 4) fix(ld_pack<T, VEC>(x + r * C + col0), r);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -288,7 +380,8 @@ static int colquant_bwd_t(const void* g, const void* x, const void* scale, const
                           long long covered, float* ws, int nchunk, void* dx, long long R, long long C, int n_bits,
                           int phase, hipStream_t stream) {
     constexpr int N = VecOf<T>::N;
-    const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(scale) && aligned16(rzp);
+    const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(scale) && aligned16(rzp) &&
+                        aligned16(ws) && aligned16(chan_min) && aligned16(chan_max);
     const float qmax = (float)((1 << n_bits) - 1);
     const int tiles = (int)(vec_ok ? (C / N + 63) / 64 : (C + 63) / 64);
     const int rpc = (int)((R + nchunk - 1) / nchunk);
