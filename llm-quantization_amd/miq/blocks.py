@@ -191,7 +191,8 @@ class _BlockBase(nn.Module):
         with torch.no_grad():
             for n, p in self.named_parameters():
                 if "smooth_scale" in n:
-                    p.data = truncate_number(p)
+                    # in place (the reference rebinds .data): the parameter keeps its storage
+                    p.copy_(truncate_number(p))
 
 
 class _OPTAttention(nn.Module):
@@ -228,7 +229,7 @@ class _OPTAttention(nn.Module):
         w = self.qkt_matmul(q, k.transpose(1, 2))
         if attention_mask is not None:
             w = w.view(bsz, self.num_heads, tgt_len, src_len) + attention_mask
-            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+            w = w.clamp(min=torch.finfo(w.dtype).min)  # torch.max against the constant, without a host-to-device copy
             w = w.view(bsz * self.num_heads, tgt_len, src_len)
         if w.dtype == torch.float16:
             w = TF.softmax(w, dim=-1, dtype=torch.float32).to(torch.float16)
@@ -415,7 +416,7 @@ class _LlamaAttention(nn.Module):
         w = self.qkt_matmul(q, k.transpose(2, 3)) / (self.head_dim ** 0.5)
         if attention_mask is not None:
             w = w + attention_mask
-            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+            w = w.clamp(min=torch.finfo(w.dtype).min)  # torch.max against the constant, without a host-to-device copy
         w = TF.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
         w = self.pv_matmul.quant_x1(w)
         v = self.pv_matmul.quant_x2(v)

@@ -52,6 +52,8 @@ class CalibConfig:
     loss_size_coef: float = 0.0
     use_shift: bool = True
     aug_loss: bool = False                 # add the MSE against the fp block applied to the QUANTIZED model's inputs
+    fused_adamw: bool = False              # torch's fused AdamW: no host synchronisation in GradScaler.step, but its
+                                           # arithmetic differs in the last bits from the default implementation
 
 
 class LossScaler:
@@ -61,8 +63,10 @@ class LossScaler:
     def __init__(self, device_type: str = "cuda"):
         self._scaler = torch.amp.GradScaler(device_type, enabled=(device_type == "cuda" and torch.cuda.is_available()))
 
-    def __call__(self, loss, optimizer, parameters, dp: Optional[DPContext] = None, buf=None):
+    def backward(self, loss):
         self._scaler.scale(loss).backward()
+
+    def step(self, optimizer, parameters, dp: Optional[DPContext] = None, buf=None):
         parameters = list(parameters)
         if dp is not None and dp.active:
             buf = allreduce_mean_grads(parameters, dp, buf)
@@ -71,6 +75,10 @@ class LossScaler:
         self._scaler.step(optimizer)
         self._scaler.update()
         return norm, buf
+
+    def __call__(self, loss, optimizer, parameters, dp: Optional[DPContext] = None, buf=None):
+        self.backward(loss)
+        return self.step(optimizer, parameters, dp, buf)
 
 
 def grad_norm(parameters, norm_type: float = 2.0):
@@ -328,11 +336,34 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
         if not cfg.weight_mix_quant:
             groups.append({"params": list(qlayer.let_parameters(cfg.use_shift)), "lr": cfg.let_lr})
         groups.append({"params": list(qlayer.lwc_parameters()), "lr": cfg.lwc_lr})
-        optimizer = torch.optim.AdamW(groups, weight_decay=cfg.wd)
+        # (fused AdamW takes GradScaler's found-inf flag on the device: a step without any host synchronisation)
+        optimizer = torch.optim.AdamW(groups, weight_decay=cfg.wd,
+                                      fused=True if (cfg.fused_adamw and dev.type == "cuda") else None)
         scaler = LossScaler("cuda" if dev.type == "cuda" else "cpu")
         buf = None
         steps_per_epoch = n_local // cfg.batch_size
         loss_size_coef = cfg.loss_size_coef
+        # per-step loss / gradient norm stay on the device until the end of the epoch
+        trace = torch.zeros((2, max(1, steps_per_epoch)), dtype=torch.float32, device=dev)
+
+        def forward_backward(xb, yb, yb2):
+            with traincast():
+                qlayer.smooth_and_quant_temporary()
+                out = qlayer(xb, attention_mask=mask_batch, position_ids=position_ids)[0]
+                loss = loss_func(yb, out)
+                if cfg.aug_loss:
+                    loss = loss + loss_func(yb2, out)
+                if cfg.weight_mix_quant:
+                    ms, ts = qlayer.get_size_loss()
+                    loss = loss + loss_func(ms, ts) * loss_size_coef
+            scaler.backward(loss)
+            return loss.detach()
+
+        def batch(j):
+            i0 = j * cfg.batch_size
+            sl = slice(i0, i0 + cfg.batch_size)
+            return quant_inps[sl], fp_inps[sl], (fp_inps_2[sl] if cfg.aug_loss else None)
+
         for epoch in range(cfg.epochs):
             if cfg.weight_mix_quant:
                 if epoch == round(cfg.epochs * 0.5):
@@ -341,27 +372,26 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                     qlayer.round_nbits()
                     loss_size_coef = 0
             for j in range(steps_per_epoch):
-                i0 = j * cfg.batch_size
-                with traincast():
-                    qlayer.smooth_and_quant_temporary()
-                    out = qlayer(quant_inps[i0:i0 + cfg.batch_size], attention_mask=mask_batch, position_ids=position_ids)[0]
-                    loss = loss_func(fp_inps[i0:i0 + cfg.batch_size], out)
-                    if cfg.aug_loss:
-                        loss = loss + loss_func(fp_inps_2[i0:i0 + cfg.batch_size], out)
-                    if cfg.weight_mix_quant:
-                        ms, ts = qlayer.get_size_loss()
-                        loss = loss + loss_func(ms, ts) * loss_size_coef
-                if not math.isfinite(loss.item()):
-                    raise FloatingPointError(f"loss became {loss.item()} at epoch {epoch}, step {j}")
                 optimizer.zero_grad()
-                norm, buf = scaler(loss, optimizer, qlayer.omni_parameters(cfg.use_shift), dp, buf)
-                losses.append(float(loss.detach()))
-                norms.append(float(norm))
+                loss = forward_backward(*batch(j))
+                norm, buf = scaler.step(optimizer, qlayer.omni_parameters(cfg.use_shift), dp, buf)
+                trace[0, j] = loss
+                trace[1, j] = norm
                 _free_act_stats(qlayer)
+            # one synchronisation per epoch: the reference tests the loss after every step
+            # (omniquant.py:518-520); a non-finite loss only makes GradScaler skip that step, so the
+            # delayed test sees the same parameters
+            ep_loss, ep_norm = trace[:, :steps_per_epoch].tolist()
+            for j, v in enumerate(ep_loss):
+                if not math.isfinite(v):
+                    raise FloatingPointError(f"loss became {v} at epoch {epoch}, step {j}")
+            losses.extend(ep_loss)
+            norms.extend(ep_norm)
             if logger is not None:
                 k = steps_per_epoch
                 logger.info(f"{layer_prefix} epoch {epoch} loss:{np.mean(losses[-k:])} norm:{np.mean(norms[-k:])}")
         qlayer.clear_temp_variable()
+        optimizer.zero_grad(set_to_none=True)
         del optimizer
     lap("train")
 

@@ -12,10 +12,8 @@ class _Truncate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, threshold):
-        out = x.clone()
-        small = out.abs() < threshold
-        out[small] = out[small].sign() * threshold
-        return out
+        # torch.where instead of the reference's masked assignment: same values, no host synchronisation
+        return torch.where(x.abs() < threshold, x.sign() * threshold, x)
 
     @staticmethod
     def backward(ctx, g):
