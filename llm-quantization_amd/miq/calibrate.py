@@ -82,11 +82,17 @@ class LossScaler:
 
 
 def grad_norm(parameters, norm_type: float = 2.0):
-    ps = [p for p in parameters if p.grad is not None]
-    if not ps:
+    """Norm of the per-parameter gradient norms (reference utils.ampscaler_get_grad_norm, utils.py:11-24);
+    the per-parameter norms come from one multi-tensor launch instead of one launch per parameter."""
+    grads = [p.grad.detach() for p in parameters if p.grad is not None]
+    if not grads:
         return torch.tensor(0.0)
-    dev = ps[0].grad.device
-    return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(dev) for p in ps]), norm_type)
+    dev = grads[0].device
+    if all(g.device == dev for g in grads):
+        per = torch.stack(torch._foreach_norm(grads, norm_type))
+    else:
+        per = torch.stack([torch.norm(g, norm_type).to(dev) for g in grads])
+    return torch.norm(per, norm_type)
 
 
 # ------------------------------------------------------------------------------------------------
