@@ -35,13 +35,14 @@ template <> __device__ __forceinline__ float bwd_div<float>(float x, float s, fl
 }
 
 // the direct path of one element: fp32 follows autograd's (g*s)/s; for fp16 gradients the plain g is within
-// their rounding (and is passed through without conversion)
-template <typename T> __device__ __forceinline__ T direct_out(T graw, float gv, float s, float rs, bool m);
-template <> __device__ __forceinline__ float direct_out<float>(float, float gv, float s, float rs, bool m) {
-    return m ? bwd_div<float>(gv * s, s, rs) : 0.f;
+// their rounding (and is passed through without conversion).  Outside the grid autograd computes 0/s, which
+// is 0 for every valid scale and NaN for a NaN scale (statistics poisoned by a NaN activation): `off`.
+template <typename T> __device__ __forceinline__ T direct_out(T graw, float gv, float s, float rs, bool m, T off);
+template <> __device__ __forceinline__ float direct_out<float>(float, float gv, float s, float rs, bool m, float off) {
+    return m ? bwd_div<float>(gv * s, s, rs) : off;
 }
-template <> __device__ __forceinline__ __half direct_out<__half>(__half graw, float, float, float, bool m) {
-    return m ? graw : __ushort_as_half((unsigned short)0);
+template <> __device__ __forceinline__ __half direct_out<__half>(__half graw, float, float, float, bool m, __half off) {
+    return m ? graw : off;
 }
 
 // dx = direct path; partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min.
@@ -100,8 +101,15 @@ k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __res
         }
     }
     const bool exact_int = __all(ok);  // wave-uniform
-    auto stream_rows = [&](auto exact_tag) {
+    // NaN scales are rare enough for a wave-uniform special case: only there the masked-out gradient is
+    // not the constant 0, and keeping it per channel in the common case costs registers this kernel lacks
+    bool finite_scales = true;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) finite_scales = finite_scales && !(valid && s[e] != s[e]);
+    const bool no_nan = __all(finite_scales);
+    auto stream_rows = [&](auto exact_tag, auto nan_tag) {
         constexpr bool EX = decltype(exact_tag)::value;
+        constexpr bool NANS = decltype(nan_tag)::value;
         auto body = [&](const Pack<T, VEC>& pa, const Pack<T, VEC>& pb, long long r) {
             Pack<T, VEC> o;
 #pragma unroll
@@ -118,7 +126,7 @@ k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __res
                 acc[e] += gv * (xd - (m ? q : rq - rq));
                 nmx[e] += (xv == cmx[e]) ? 1 : 0;
                 nmn[e] += (xv == cmn[e]) ? 1 : 0;
-                o.e[e] = direct_out<T>(pb.e[e], gv, s[e], rs[e], m);
+                o.e[e] = direct_out<T>(pb.e[e], gv, s[e], rs[e], m, NANS ? from_f<T>(0.f / s[e]) : from_f<T>(0.f));
             }
             st_pack<T, VEC>(dx + r * C + col0, o);
         };
@@ -133,8 +141,11 @@ k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __res
         }
     };
     if (valid) {
-        if (sizeof(T) == 4 || exact_int) stream_rows(std::true_type{});
-        else stream_rows(std::false_type{});
+        const bool ex = sizeof(T) == 4 || exact_int;
+        if (ex && no_nan) stream_rows(std::true_type{}, std::false_type{});
+        else if (ex) stream_rows(std::true_type{}, std::true_type{});
+        else if (no_nan) stream_rows(std::false_type{}, std::false_type{});
+        else stream_rows(std::false_type{}, std::true_type{});
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -256,11 +267,13 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
     float s[VEC], rs[VEC], z[VEC];
+    T off[VEC];
     Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         s[e] = to_f<T>(ps.e[e]);
         rs[e] = 1.0f / s[e];
+        off[e] = from_f<T>(0.f / s[e]);
         z[e] = to_f<T>(pz.e[e]);
     }
     auto body = [&](const Pack<T, VEC>& a, const Pack<T, VEC>& b, long long r) {
@@ -270,7 +283,7 @@ k_colbwd_apply(const T* __restrict__ x, const T* __restrict__ g, const T* __rest
             const float xv = to_f<T>(a.e[e]), gv = to_f<T>(b.e[e]);
             const float xi = rnd<T>(rint_ste(bwd_div<T>(xv, s[e], rs[e])) + z[e]);
             const bool m = (xi >= 0.f) && (xi <= qmax);
-            o.e[e] = direct_out<T>(b.e[e], gv, s[e], rs[e], m);
+            o.e[e] = direct_out<T>(b.e[e], gv, s[e], rs[e], m, off[e]);
         }
         st_pack<T, VEC>(dx + r * C + col0, o);
     };

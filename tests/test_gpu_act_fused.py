@@ -107,3 +107,35 @@ def test_workspace_size_matches_chunks():
     for (R, C, dt) in ((2048, 4096, torch.float32), (7, 24, torch.float16)):
         n = int(L.lib().miq_act_workspace(L.i64(R), L.i64(C), L.i32(L._DT[dt])))
         assert n == 2 * (F.colstat_chunks(R, C, dt) + 1) * C
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("bad", ["inf", "nan"])
+def test_backward_with_non_finite_activations(dt, bad):
+    """+-inf / NaN activations: the statistics, scales and the backward follow PyTorch's propagation rules
+    (inf saturates the clamped scale and turns its own level into NaN through round_ste; NaN poisons the
+    statistics of its cluster).  The positions of NaN in dx and the finite entries must match autograd."""
+    dtype = DT[dt]
+    R, C, bits = 96, 256, 4
+    counts = [64] * 4
+    layout = F.ClusterLayout.get(counts, C, DEV)
+    x = synth.activation((R, C), 77, dtype)
+    if bad == "inf":
+        x[3, 5] = float("inf")
+        x[40, 200] = float("-inf")
+    else:
+        x[3, 5] = float("nan")
+    g = synth.grad_like(x, 78)
+    xd, gd = x.to(DEV), g.to(DEV)
+    out, _, st = F.act_calib_quant_fwd(xd, bits, "minmax", layout)
+    xr = x.clone().requires_grad_(True)
+    ref, _ = O.act_forward(xr, O.ActState(), bits, "calibration", method="per_cluster", metric="minmax", cluster_dim=1,
+                           cluster_counts=counts)
+    assert same(out.cpu(), ref.detach())
+    dx = F.colquant_bwd(gd, xd, st["scale"], st["rzp"], bits,
+                        route=(st["chan_min"], st["chan_max"], st["cmin"], st["cmax"], layout)).cpu()
+    (ref_dx,) = torch.autograd.grad((ref.float() * g.float()).sum(), [xr])
+    assert torch.equal(torch.isnan(dx), torch.isnan(ref_dx))
+    ok = torch.isfinite(ref_dx)
+    z = torch.zeros_like(ref_dx)
+    assert rel_err(torch.where(ok, dx, z), torch.where(ok, ref_dx, z)) <= (5e-3 if dtype == torch.float32 else 2e-2)
