@@ -96,7 +96,7 @@ template <typename T> __device__ __forceinline__ float sigmoid_t(float x) {
 
 // ---------------------------------------------------------------------------------------------
 // x / s rounded to T, for a divisor that is reused many times.
-//   float: plain IEEE division.
+//   float: plain IEEE division (the kernels that use it are bound by memory, the ~12 VALU ops are hidden).
 //   half : x and s carry 11-bit significands, so one Newton correction on a product with the
 //          correctly rounded reciprocal gives EXACTLY the IEEE fp32 quotient: the residual
 //          e = x - q0*s is exact in an fma, and the true quotient of two 11-bit numbers can never sit
@@ -109,6 +109,44 @@ template <> struct Divisor<float> {
     __device__ __forceinline__ explicit Divisor(float s_) : s(s_) {}
     __device__ __forceinline__ float div(float x) const { return x / s; }
 };
+// The fp32 quotient for kernels that are bound by arithmetic (exponent and mixed-bit grids): the correctly
+// rounded reciprocal rs = RN(1/s) and one FMA correction (Markstein): q0 = x*rs, r = fma(-q0, s, x) (exact),
+// q = fma(r, rs, q0); 5 VALU ops with the range test.  Bit-identical to x / s whenever 2^-40 <= |s| <= 2^40 and
+// 2^-80 <= |q0| <= 2^100 (tools/ubench/divcheck.hip: 1.4e11 random operand pairs and all 2^23 significands of x
+// against 32 special divisors, no mismatch); everything else (zeros, infinities, NaN, quotients near the ends of
+// the exponent range) takes the plain division.  The branch costs a few percent where the division was hidden
+// behind memory traffic, which is why the uniform kernels keep Divisor<float>.
+struct CorrectedDivisor {
+    float s, rs;
+    bool fast;
+    __device__ __forceinline__ explicit CorrectedDivisor(float s_) : CorrectedDivisor(s_, 1.0f / s_) {}
+    // rs_ must be the IEEE quotient 1.0f / s_
+    __device__ __forceinline__ CorrectedDivisor(float s_, float rs_) : s(s_), rs(rs_) {
+        const float a = fabsf(s_);
+        fast = (a >= 0x1p-40f) && (a <= 0x1p40f);
+    }
+    __device__ __forceinline__ float div(float x) const {
+        const float q0 = x * rs;
+        const float a = fabsf(q0);
+        if (fast && a >= 0x1p-80f && a <= 0x1p100f) return __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
+        return x / s;
+    }
+};
+// The same product without the range test, for backward passes (gradients are tolerance-checked sums; equal to
+// the IEEE quotient for every finite operand pair away from the ends of the exponent range)
+struct UncheckedDivisor {
+    float s, rs;
+    __device__ __forceinline__ explicit UncheckedDivisor(float s_) : s(s_), rs(1.0f / s_) {}
+    __device__ __forceinline__ float div(float x) const {
+        const float q0 = x * rs;
+        return __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
+    }
+};
+// divisor types of the arithmetic-bound row kernels
+template <typename T> struct BwdDivisorOf { using type = Divisor<T>; };
+template <> struct BwdDivisorOf<float> { using type = UncheckedDivisor; };
+template <typename T> struct FastDivisorOf { using type = Divisor<T>; };
+template <> struct FastDivisorOf<float> { using type = CorrectedDivisor; };
 template <> struct Divisor<__half> {
     float s, rs;
     bool fast;

@@ -27,6 +27,14 @@ struct ExpArgs {
     int preact;
 };
 
+// v / 1.5f as the IEEE quotient through the corrected reciprocal product (see CorrectedDivisor; v lies in
+// [1e-4, 1e4] here, far inside the range where the correction is exact)
+__device__ __forceinline__ float div_1p5(float v) {
+    constexpr float kInv = 1.0f / 1.5f;  // correctly rounded at compile time
+    const float q0 = v * kInv;
+    return __builtin_fmaf(__builtin_fmaf(-q0, 1.5f, v), kInv, q0);
+}
+
 // ------------------------------------------------------------------------------------------ v2
 struct Exp2Ctx {
     ClipCtx clip;
@@ -50,15 +58,15 @@ struct Exp2Elem {
     bool is_zero, below;
 };
 
-template <typename T>
-__device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c, const Divisor<T>& dv) {
+template <typename T, class D>
+__device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c, const D& dv) {
     Exp2Elem r;
     const float q = dv.div(xv);
     r.sign = sgnf(q);
     const float a0 = fabsf(q);
     r.is_zero = a0 < 0.5f;
     r.mag = clampf(a0, rnd<T>(1e-4f), 1e4f);
-    float t = rnd<T>(rnd<T>(__log2f(rnd<T>(r.mag / 1.5f))) + 0.5f);
+    float t = rnd<T>(rnd<T>(__log2f(rnd<T>(div_1p5(r.mag)))) + 0.5f);
     r.below = t < -0.5f;
     if (r.below) t = 0.f;
     float e = (t == t) ? ldexpf(1.0f, (int)rintf(t)) : t;  // 2^integer: exact and representable in T (t <= 14); NaN stays NaN
@@ -84,7 +92,7 @@ k_exp2_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
-    const Divisor<T> dv(c.s);
+    const typename FastDivisorOf<T>::type dv(c.s);
     if (lane == 0) scale_out[row] = from_f<T>(c.s);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -120,7 +128,7 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     float rmin, rmax;
     row_minmax(x, padded, lds, rmin, rmax);
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
-    const Divisor<T> dv(c.s);
+    const typename BwdDivisorOf<T>::type dv(c.s);
     auto grad_q = [&](float gv, const Exp2Elem& el) {
         float gq = gv * c.s;
         if (el.sign == -1.f) gq = -gq;
@@ -216,8 +224,8 @@ struct Exp1Elem {
     float v, u, sign, mag, lround, p;  // v = x - mid, u = v/s, mag = clamp|u|, lround = round(log2 mag), p = 2^e
 };
 
-template <typename T>
-__device__ __forceinline__ Exp1Elem exp1_elem(float xv, const Exp1Ctx& c, const Divisor<T>& dv) {
+template <typename T, class D>
+__device__ __forceinline__ Exp1Elem exp1_elem(float xv, const Exp1Ctx& c, const D& dv) {
     Exp1Elem r;
     r.v = c.has_mid ? rnd<T>(xv - c.mid) : xv;
     r.sign = sgnf(r.v);
@@ -253,7 +261,7 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
-    const Divisor<T> dv(c.s);
+    const typename FastDivisorOf<T>::type dv(c.s);
     if (lane == 0) {
         scale_out[row] = from_f<T>(c.s);
         if (mid_out) mid_out[row] = from_f<T>(c.mid);
@@ -291,7 +299,7 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     float rmin, rmax;
     row_minmax(x, padded, lds, rmin, rmax);
     const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
-    const Divisor<T> dv(c.s);
+    const typename BwdDivisorOf<T>::type dv(c.s);
     const float alo = rnd<T>(kClipLo);
     auto d_u = [&](float gv, const Exp1Elem& el) {
         const bool live = (el.lround >= c.e_lo) && (el.lround <= 0.f) && (fabsf(el.u) >= alo) && (fabsf(el.u) <= kClipHi);

@@ -29,7 +29,7 @@ struct MixArgs {
 };
 
 struct Grid {
-    float b, Q, H, s, s_raw, z, w;  // bits, 2^b-1, 2^(b-1)-1, scale, unclamped scale, zero point, blend weight
+    float b, Q, H, s, s_raw, z, w, rs;  // bits, 2^b-1, 2^(b-1)-1, scale, unclamped scale, zero point, blend weight, 1/scale
 };
 
 struct MixCtx {
@@ -52,6 +52,7 @@ __device__ __forceinline__ void make_grid(Grid& gr, float b, float w, const MixC
         gr.s = clampf(gr.s_raw, kClipLo, kClipHi);
         gr.z = rintf(clampf(-c.clip.xmin / gr.s, -kClipHi, kClipHi));
     }
+    gr.rs = 1.0f / gr.s;
 }
 
 __device__ __forceinline__ MixCtx mix_ctx(const MixArgs& a, long long row, float rmin, float rmax) {
@@ -74,7 +75,7 @@ __device__ __forceinline__ MixCtx mix_ctx(const MixArgs& a, long long row, float
 }
 
 __device__ __forceinline__ float grid_level(float xv, const Grid& gr) {
-    const float q = xv / gr.s;
+    const float q = CorrectedDivisor(gr.s, gr.rs).div(xv);
     return ((rintf(q) - q) + q) + gr.z;
 }
 __device__ __forceinline__ float grid_fq(float xv, const Grid& gr) {
@@ -133,13 +134,16 @@ k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restr
     // returns the straight-through part of dx through this grid (what autograd forms as ((g*w)*s)/s)
     auto terms = [&](float xv, float gv, const Grid& gr, float& dS, float& over) {
         const float gb = gv * gr.w;
-        const float q = xv / gr.s;
+        // backward: the corrected reciprocal product without the range test of Divisor<float> (equal to the IEEE
+        // quotient for every weight a forward pass can quantize; gradients are tolerance-checked sums)
+        const float q0 = xv * gr.rs;
+        const float q = __builtin_fmaf(__builtin_fmaf(-q0, gr.s, xv), gr.rs, q0);
         const float xi = ((rintf(q) - q) + q) + gr.z;
         const bool m = (xi >= 0.f) && (xi <= gr.Q);
         const float xd = clampf(xi, 0.f, gr.Q) - gr.z;
         dS += gb * (xd - (m ? q : 0.f));
         if (xi > gr.Q) over += gb * gr.s;
-        return m ? (gb * gr.s) / gr.s : 0.f;
+        return m ? (gb * gr.s) * gr.rs : 0.f;
     };
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
