@@ -263,6 +263,23 @@ int miq_let_rowquant_bwd(const void* grad_out, const float* g_wshift, const floa
  */
 int miq_row_absmean_accum(const void* g, float* acc, int64_t O, int64_t I, int dtype, void* stream);
 
+/*
+ * The attention-score chain of the decoder blocks between the quantized q·k^T and p·v matmuls
+ * (models/int_llama_layer.py:139-154, models/int_opt_layer.py:199-221):
+ *   p = softmax(max(x / div + mask, finfo.min), dim=-1, dtype=float32).to(x dtype)
+ * in one pass.  x, out: [R, C] scores / probabilities (fp32 or fp16), R = batch*heads*q_len rows of C keys;
+ * mask: [R / rows_per_batch * q_len, C] fp32 or fp16 (the [B, 1, q_len, C] attention mask: the
+ * rows_per_batch = heads*q_len score rows of one batch entry share its q_len mask rows) or NULL (then no
+ * floor either); div = sqrt(head_dim) for Llama, 1 for OPT (which scales q before the matmul).  x / div is
+ * formed as x * (1/div) like ATen's tensor / scalar on a GPU and rounded to x's dtype.  C a multiple of 4 (fp32)
+ * or 8 (fp16).
+ * Backward: dx = p * (grad_out - sum_j grad_out_j p_j) / div from the saved probabilities.
+ */
+int miq_masked_softmax_fwd(const void* x, const void* mask, void* out, int64_t R, int64_t C, int64_t rows_per_batch,
+                           int64_t q_len, float div, int x_dtype, int mask_dtype, void* stream);
+int miq_masked_softmax_bwd(const void* p, const void* grad_out, void* dx, int64_t R, int64_t C, float div, int dtype,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,216 @@
+// Attention-score chain of the decoder blocks between the two quantized matmuls, in one pass per direction:
+//     w = scores / sqrt(head_dim)        (Llama only; reference models/int_llama_layer.py:139)
+//     w = w + attention_mask             (broadcast over heads)
+//     w = max(w, finfo.min)              (int_llama_layer.py:149-151, int_opt_layer.py:207-210)
+//     p = softmax(w, dim=-1, dtype=float32).to(scores.dtype)
+// PyTorch runs these as five elementwise / reduction kernels over the [heads*T, T] score matrix (134 M elements
+// for a Llama-2-7B block: ~4.8 GB of traffic forward, ~4 GB backward); here a team of threads owns one row, keeps
+// it in registers, and the row crosses HBM once in each direction.
+//
+// Arithmetic: every step in fp32 on the values PyTorch would see (the fp16 quotient by sqrt(head_dim) is rounded
+// to fp16 first, and formed as a product with the fp32 reciprocal like ATen's tensor / scalar on a GPU); max / sum
+// reductions in fp32.  The summation order of
+// the softmax differs from ATen's, so probabilities agree to fp32 rounding, not bit for bit (these operators are
+// not quantizer arithmetic; the blocks' tests compare them with the PyTorch chain).
+// Backward from the saved probabilities p (output dtype) and the incoming gradient g:
+//     dw = p * (g - sum_j g_j p_j) / sqrt(head_dim)
+// (positions cut by the max(., finfo.min) have p == 0, hence no gradient, like the reference's clamp mask).
+#include "miq_common.h"
+
+namespace miq {
+
+struct SmArgs {
+    const void* x;       // [R, C] scores
+    const void* mask;    // [mask_batches * q_len, C] or nullptr
+    int mask_half;       // mask is fp16 (else fp32)
+    int sum_half;        // scores + mask is an fp16 tensor (both operands fp16): round the sum to fp16
+    float inv_div;       // reciprocal of the divisor applied first (1 = none): ATen multiplies by 1/scalar on the GPU
+    float floor_;        // the lower clamp (finfo.min of the sum's dtype)
+    long long R;
+    int C;
+    long long rows_per_batch;  // heads * q_len score rows share one batch entry of the mask
+    int q_len;
+};
+
+struct OpMaxNan {
+    __device__ float operator()(int, float a, float b) const { return nmax(a, b); }
+};
+
+__device__ __forceinline__ long long mask_row(const SmArgs& a, long long row) {
+    return (row / a.rows_per_batch) * a.q_len + row % a.q_len;
+}
+
+template <typename TX, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_masked_softmax_fwd(SmArgs a, TX* __restrict__ out) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    // TEAM > 64 implies RPB == 1: a block is one row, so this exit is block-uniform where barriers follow
+    if (row >= a.R) return;
+    RowTile<TX, VEC, TEAM, NV> x;
+    x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
+    const long long mrow = a.mask ? mask_row(a, row) : 0;
+    float v[NV][VEC];
+    float mx[1] = {-__builtin_inff()};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+        float mv[VEC];
+        if (a.mask) {
+            if (a.mask_half) {
+                const Pack<__half, VEC> m = ld_pack<__half, VEC>(reinterpret_cast<const __half*>(a.mask) + mrow * a.C + x.offset(k));
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) mv[e] = __half2float(m.e[e]);
+            } else {
+                const float* mp = reinterpret_cast<const float*>(a.mask) + mrow * a.C + x.offset(k);
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {  // 16-byte loads: VEC is 4 or 8
+                    const Pack<float, 4> m = ld_pack<float, 4>(mp + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mv[4 * q + e] = m.e[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float t = to_f<TX>(x.v[k].e[e]);
+            if (a.inv_div != 1.0f) t = rnd<TX>(t * a.inv_div);
+            if (a.mask) {
+                t = t + mv[e];
+                if (a.sum_half) t = rnd<__half>(t);
+            }
+            t = (t < a.floor_) ? a.floor_ : t;  // torch.max(w, finfo.min): NaN stays NaN
+            v[k][e] = t;
+            mx[0] = nmax(mx[0], t);
+        }
+    }
+    team_reduce<TEAM, 1>(mx, OpMaxNan(), lds);
+    float sum[1] = {0.f};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[k][e] = __expf(v[k][e] - mx[0]);
+            sum[0] += v[k][e];
+        }
+    }
+    team_sum<TEAM, 1>(sum, lds);
+    const float inv = 1.0f / sum[0];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+        Pack<TX, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<TX>(v[k][e] * inv);
+        st_pack<TX, VEC>(out + row * a.C + x.offset(k), o);
+    }
+}
+
+template <typename TX, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_masked_softmax_bwd(const TX* __restrict__ p, const TX* __restrict__ g, TX* __restrict__ dx, long long R, int C, float div) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= R) return;
+    RowTile<TX, VEC, TEAM, NV> pp, gg;
+    pp.load_nt(p + row * C, C, lane);
+    gg.load_nt(g + row * C, C, lane);
+    float dot[1] = {0.f};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!pp.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dot[0] += to_f<TX>(pp.v[k].e[e]) * to_f<TX>(gg.v[k].e[e]);
+    }
+    team_sum<TEAM, 1>(dot, lds);
+    const float inv_div = 1.0f / div;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!pp.has(k)) continue;
+        Pack<TX, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float pv = to_f<TX>(pp.v[k].e[e]);
+            o.e[e] = from_f<TX>((pv * (to_f<TX>(gg.v[k].e[e]) - dot[0])) * inv_div);
+        }
+        st_pack<TX, VEC>(dx + row * C + pp.offset(k), o);
+    }
+}
+
+template <typename TX>
+static int launch_sm_fwd(const SmArgs& a, void* out, hipStream_t stream) {
+    constexpr int VEC = VecOf<TX>::N;
+    const int npack = a.C / VEC;
+#define L(TEAM, NV)                                                                                               \
+    {                                                                                                             \
+        constexpr int RPB = block_of<TEAM>() / TEAM;                                                              \
+        hipLaunchKernelGGL((k_masked_softmax_fwd<TX, VEC, TEAM, NV>), dim3((unsigned)((a.R + RPB - 1) / RPB)),    \
+                           dim3(block_of<TEAM>()), 0, stream, a, (TX*)out);                                       \
+    }
+    MIQ_ROW_DISPATCH(npack, L);
+#undef L
+    MIQ_CHECK_LAUNCH("miq_masked_softmax_fwd");
+    return 0;
+}
+
+template <typename TX>
+static int launch_sm_bwd(const void* p, const void* g, void* dx, long long R, int C, float div, hipStream_t stream) {
+    constexpr int VEC = VecOf<TX>::N;
+    const int npack = C / VEC;
+#define L(TEAM, NV)                                                                                               \
+    {                                                                                                             \
+        constexpr int RPB = block_of<TEAM>() / TEAM;                                                              \
+        hipLaunchKernelGGL((k_masked_softmax_bwd<TX, VEC, TEAM, NV>), dim3((unsigned)((R + RPB - 1) / RPB)),      \
+                           dim3(block_of<TEAM>()), 0, stream, (const TX*)p, (const TX*)g, (TX*)dx, R, C, div);    \
+    }
+    MIQ_ROW_DISPATCH(npack, L);
+#undef L
+    MIQ_CHECK_LAUNCH("miq_masked_softmax_bwd");
+    return 0;
+}
+
+}  // namespace miq
+
+using namespace miq;
+
+extern "C" int miq_masked_softmax_fwd(const void* x, const void* mask, void* out, int64_t R, int64_t C, int64_t rows_per_batch,
+                                      int64_t q_len, float div, int x_dtype, int mask_dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(x && out && R > 0 && C > 0, "miq_masked_softmax_fwd: null pointer or bad shape");
+    MIQ_CHECK_ARG(x_dtype == MIQ_F32 || x_dtype == MIQ_F16, "miq_masked_softmax_fwd: unsupported dtype %d", x_dtype);
+    const int vec = x_dtype == MIQ_F16 ? 8 : 4;
+    MIQ_CHECK_ARG(C % vec == 0 && C / vec <= kRowMaxPacks && C < (1ll << 31),
+                  "miq_masked_softmax_fwd: C=%lld must be a multiple of %d and at most %d", (long long)C, vec, vec * kRowMaxPacks);
+    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(out) && is_aligned16(mask), "miq_masked_softmax_fwd: pointers must be 16-byte aligned");
+    MIQ_CHECK_ARG(!mask || ((mask_dtype == MIQ_F32 || mask_dtype == MIQ_F16) && q_len > 0 && rows_per_batch > 0 &&
+                            rows_per_batch % q_len == 0 && R % rows_per_batch == 0),
+                  "miq_masked_softmax_fwd: mask needs q_len > 0 and rows_per_batch (a multiple of q_len) dividing R");
+    MIQ_CHECK_ARG(div > 0.f, "miq_masked_softmax_fwd: divisor must be positive");
+    SmArgs a;
+    a.x = x; a.mask = mask; a.mask_half = mask_dtype == MIQ_F16;
+    a.sum_half = (x_dtype == MIQ_F16 && mask_dtype == MIQ_F16);
+    a.inv_div = 1.0f / div;
+    a.floor_ = !mask ? -__builtin_inff() : (a.sum_half ? -65504.0f : -3.4028234663852886e38f);
+    a.R = R; a.C = (int)C; a.rows_per_batch = mask ? rows_per_batch : 1; a.q_len = mask ? (int)q_len : 1;
+    if (x_dtype == MIQ_F32) return launch_sm_fwd<float>(a, out, (hipStream_t)stream);
+    return launch_sm_fwd<__half>(a, out, (hipStream_t)stream);
+}
+
+extern "C" int miq_masked_softmax_bwd(const void* p, const void* grad_out, void* dx, int64_t R, int64_t C, float div, int dtype,
+                                      void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(p && grad_out && dx && R > 0 && C > 0, "miq_masked_softmax_bwd: null pointer or bad shape");
+    MIQ_CHECK_ARG(dtype == MIQ_F32 || dtype == MIQ_F16, "miq_masked_softmax_bwd: unsupported dtype %d", dtype);
+    const int vec = dtype == MIQ_F16 ? 8 : 4;
+    MIQ_CHECK_ARG(C % vec == 0 && C / vec <= kRowMaxPacks && C < (1ll << 31),
+                  "miq_masked_softmax_bwd: C=%lld must be a multiple of %d and at most %d", (long long)C, vec, vec * kRowMaxPacks);
+    MIQ_CHECK_ARG(is_aligned16(p) && is_aligned16(grad_out) && is_aligned16(dx), "miq_masked_softmax_bwd: pointers must be 16-byte aligned");
+    MIQ_CHECK_ARG(div > 0.f, "miq_masked_softmax_bwd: divisor must be positive");
+    if (dtype == MIQ_F32) return launch_sm_bwd<float>(p, grad_out, dx, R, (int)C, div, (hipStream_t)stream);
+    return launch_sm_bwd<__half>(p, grad_out, dx, R, (int)C, div, (hipStream_t)stream);
+}

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from . import functional as F
 from .int_linear import QuantLinear
 from .int_matmul import QuantMatMul
 from .let import (smooth_fc_fc_inplace, smooth_fc_fc_temporary, smooth_ln_fcs_inplace, smooth_ln_fcs_temporary,
@@ -212,6 +213,7 @@ class _OPTAttention(nn.Module):
         self.out_proj = QuantLinear(o, args.weight_quant_params, args.act_quant_params, False, weight_nbits=nb.get("o", []), **kw)
         self.qkt_matmul = QuantMatMul(args.q_quant_params, args.k_quant_params, matmul_func=torch.bmm)
         self.pv_matmul = QuantMatMul(args.p_quant_params, args.v_quant_params, matmul_func=torch.bmm)
+        self.fused_softmax = True
 
     def _heads(self, t, bsz):
         return t.view(bsz, -1, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
@@ -227,14 +229,21 @@ class _OPTAttention(nn.Module):
         v = v.view(*shape)
         src_len = k.size(1)
         w = self.qkt_matmul(q, k.transpose(1, 2))
-        if attention_mask is not None:
-            w = w.view(bsz, self.num_heads, tgt_len, src_len) + attention_mask
-            w = w.clamp(min=torch.finfo(w.dtype).min)  # torch.max against the constant, without a host-to-device copy
-            w = w.view(bsz * self.num_heads, tgt_len, src_len)
-        if w.dtype == torch.float16:
-            w = TF.softmax(w, dim=-1, dtype=torch.float32).to(torch.float16)
+        w4 = w.view(bsz, self.num_heads, tgt_len, src_len)
+        # the fused pass returns the scores' dtype: usable when the mask does not promote them (fp16 scores + fp32
+        # mask give fp32 probabilities in this block, unlike the Llama block which casts back)
+        same_dtype = attention_mask is None or attention_mask.dtype == w.dtype
+        if self.fused_softmax and same_dtype and F.masked_softmax_supported(w4, attention_mask):
+            w = F.MaskedSoftmax.apply(w4, attention_mask, 1.0).view(bsz * self.num_heads, tgt_len, src_len)
         else:
-            w = TF.softmax(w, dim=-1)
+            if attention_mask is not None:
+                w = w4 + attention_mask
+                w = w.clamp(min=torch.finfo(w.dtype).min)  # torch.max against the constant, without a host-to-device copy
+                w = w.view(bsz * self.num_heads, tgt_len, src_len)
+            if w.dtype == torch.float16:
+                w = TF.softmax(w, dim=-1, dtype=torch.float32).to(torch.float16)
+            else:
+                w = TF.softmax(w, dim=-1)
         w = self.pv_matmul.quant_x1(w)
         o = self.pv_matmul(w, v)
         o = o.view(bsz, self.num_heads, tgt_len, self.head_dim).transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
@@ -397,6 +406,7 @@ class _LlamaAttention(nn.Module):
         self.o_proj = QuantLinear(o, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("o", []), **kw)
         self.qkt_matmul = QuantMatMul(args.q_quant_params, args.k_quant_params, matmul_func=torch.matmul)
         self.pv_matmul = QuantMatMul(args.p_quant_params, args.v_quant_params, matmul_func=torch.matmul)
+        self.fused_softmax = True
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None):
         bsz, q_len, _ = hidden_states.size()
@@ -413,11 +423,16 @@ class _LlamaAttention(nn.Module):
             v = v.reshape(bsz, self.num_heads, q_len, self.head_dim)
         q = self.qkt_matmul.quant_x1(q)
         k = self.qkt_matmul.quant_x2(k)
-        w = self.qkt_matmul(q, k.transpose(2, 3)) / (self.head_dim ** 0.5)
-        if attention_mask is not None:
-            w = w + attention_mask
-            w = w.clamp(min=torch.finfo(w.dtype).min)  # torch.max against the constant, without a host-to-device copy
-        w = TF.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+        w = self.qkt_matmul(q, k.transpose(2, 3))
+        if self.fused_softmax and F.masked_softmax_supported(w, attention_mask):
+            # scale, mask, floor, fp32 softmax and the cast back in one pass over the score matrix
+            w = F.MaskedSoftmax.apply(w, attention_mask, self.head_dim ** 0.5)
+        else:
+            w = w / (self.head_dim ** 0.5)
+            if attention_mask is not None:
+                w = w + attention_mask
+                w = w.clamp(min=torch.finfo(w.dtype).min)  # torch.max against the constant, without a host-to-device copy
+            w = TF.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
         w = self.pv_matmul.quant_x1(w)
         v = self.pv_matmul.quant_x2(v)
         o = self.pv_matmul(w, v)

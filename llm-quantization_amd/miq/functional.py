@@ -443,6 +443,49 @@ class GatherLayerNorm(torch.autograd.Function):
         return dx, None, None, dw if mask[1] else None, db if mask[2] else None, None, None
 
 
+def masked_softmax_supported(scores, mask) -> bool:
+    C = scores.shape[-1]
+    ok = scores.is_cuda and scores.dtype in (torch.float16, torch.float32) and scores.dim() == 4
+    ok = ok and C % (8 if scores.dtype == torch.float16 else 4) == 0 and C <= 16384
+    if mask is not None:
+        ok = ok and mask.is_cuda and mask.dtype in (torch.float16, torch.float32) and mask.dim() == 4
+        ok = ok and mask.shape[1] == 1 and mask.shape[0] in (1, scores.shape[0]) and tuple(mask.shape[2:]) == tuple(scores.shape[2:])
+        ok = ok and not (scores.dtype == torch.float32 and mask.dtype == torch.float16)
+    return bool(ok)
+
+
+class MaskedSoftmax(torch.autograd.Function):
+    """softmax(max(scores / div + mask, finfo.min), dim=-1, dtype=float32).to(scores.dtype) for [B, H, Q, K]
+    scores and a [B or 1, 1, Q, K] mask (or None), one kernel per direction (miq_masked_softmax_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, scores, mask, div):
+        x = scores.contiguous()
+        B, H, Q, K = x.shape
+        out = torch.empty_like(x)
+        m = None
+        if mask is not None:
+            m = mask.expand(B, 1, Q, K).contiguous() if mask.shape[0] != B and B > 1 else mask.contiguous()
+        dev = L.check_gpu(x, m)
+        with torch.cuda.device(dev):
+            L.call("miq_masked_softmax_fwd", L.ptr(x), L.ptr(m), L.ptr(out), L.i64(B * H * Q), L.i64(K), L.i64(H * Q), L.i64(Q),
+                   L.f32(float(div)), L.i32(L.dtype_code(x)), L.i32(L.dtype_code(m) if m is not None else L.F32), L.stream_of(x))
+        ctx.save_for_backward(out)
+        ctx.div = float(div)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(p)
+        K = p.shape[-1]
+        with torch.cuda.device(p.device):
+            L.call("miq_masked_softmax_bwd", L.ptr(p), L.ptr(g), L.ptr(dx), L.i64(p.numel() // K), L.i64(K), L.f32(ctx.div),
+                   L.i32(L.dtype_code(p)), L.stream_of(p))
+        return dx, None, None
+
+
 class ActEvalFQ(torch.autograd.Function):
     """Frozen per-channel scales: out = fq(x); dx = g * [level inside the grid]."""
 

@@ -32,10 +32,17 @@ def build(d):
     return QuantOPTBlock(w, m["heads"], args).to(DEV)
 
 
-def test_tiny_opt_block_matches_reference_run():
+@pytest.mark.parametrize("fused_softmax", [False, True])
+def test_tiny_opt_block_matches_reference_run(fused_softmax):
+    """fused_softmax=False keeps ATen's softmax, the arithmetic closest to the fixture's; with the fused
+    attention-score pass the fp32 summation order of the softmax changes, which this 64-wide block amplifies
+    like any other rounding difference (a flipped 4-bit activation code moves the last losses by ~2 %), so
+    the loss / norm bounds are doubled there."""
     d = golden("block")["opt_tiny_w4a4_reorder"]
     m = d["meta"]
     q = build(d)
+    q.self_attn.fused_softmax = fused_softmax
+    slack = 2.0 if fused_softmax else 1.0
     R.oc_maxmin_dict.clear()
     R.ic_maxmin_dict.clear()
     for name in ("self_attn_layer_norm", "self_attn.q_proj", "self_attn.k_proj", "final_layer_norm"):
@@ -61,8 +68,8 @@ def test_tiny_opt_block_matches_reference_run():
     assert rel_err(fp_inps, d["fp_out"]) <= 1e-5
     losses = torch.tensor(res["losses"])
     norms = torch.tensor(res["norms"])
-    assert torch.allclose(losses, d["losses"], rtol=2e-2), (losses, d["losses"])
-    assert torch.allclose(norms, d["norms"], rtol=5e-2), (norms, d["norms"])
+    assert torch.allclose(losses, d["losses"], rtol=2e-2 * slack), (losses, d["losses"])
+    assert torch.allclose(norms, d["norms"], rtol=5e-2 * slack), (norms, d["norms"])
     assert float(losses[-4:].mean()) < float(losses[:4].mean())  # it learns
     # learned parameters (the fixture stores them before the final .half())
     state = res["omni_state"]
@@ -76,7 +83,7 @@ def test_tiny_opt_block_matches_reference_run():
         # the bulk must agree tightly and single elements may differ by a few learning-rate steps
         err = (got - ref).abs()
         bound = 2e-3 + 1e-3 * ref.abs().max().item()
-        assert (err <= bound).float().mean().item() >= 0.98, k
+        assert (err <= bound).float().mean().item() >= (0.95 if fused_softmax else 0.98), k
         assert err.max().item() <= 4e-2, k
         assert state[k].dtype == torch.float16
     # the last optimizer steps already differ in the 3rd digit (GPU vs CPU GEMM rounding flips codes,
