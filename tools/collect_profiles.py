@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Installs one round's measurement directory (as written by the collection command in profiles/README.md)
+into profiles/: bench line, kernel-trace summary, the library's rows of the two PMC passes, the per-kernel
+traffic summary, the per-family traffic file that bench.py reads, and the family table.
+
+usage: collect_profiles.py <gpurun_out/dir> <tag, e.g. r01_e>
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    prof = os.path.join(REPO, "profiles")
+    shutil.copy(os.path.join(src, "bench.json.log"), os.path.join(prof, f"{tag}_bench.json.log"))
+    shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0], os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "families.json"), os.path.join(prof, f"{tag}_families.json"))
+    extra = os.path.join(src, "blocks_extra.jsonl")
+    if os.path.exists(extra):
+        shutil.copy(extra, os.path.join(prof, f"{tag}_blocks_extra.jsonl"))
+    paths = {}
+    for name in ("fetch", "write"):
+        path = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))[0]
+        paths[name] = path
+        rows = list(csv.DictReader(open(path)))
+        keep = [r for r in rows if "miq::" in r["Kernel_Name"]]
+        with open(os.path.join(prof, f"{tag}_pmc_{name}_size.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=rows[0].keys())
+            w.writeheader()
+            w.writerows(keep)
+    per_kernel = os.path.join(prof, f"{tag}_pmc_traffic_per_kernel.json")
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summary.py"), paths["fetch"], paths["write"], per_kernel],
+                   check=True, stdout=subprocess.DEVNULL)
+    fam = json.load(open(per_kernel))["families_total_bytes"]
+    steps = 3  # --steps 2 --warmup 1 in eager mode: every step is dispatched and counted
+    t = {"_per": "step"}
+    for k in ("act_bwd", "act_calib_quant_fwd", "rowquant_bwd", "rowquant_fwd"):
+        t[k] = round((fam[k]["read"] + fam[k]["write"]) / steps)
+    g = round((fam["gather"]["read"] + fam["gather"]["write"]) / steps / 2)
+    t["gather_fwd"] = t["gather_bwd"] = g
+    t["_source"] = ("HBM bytes per bench step and kernel family = sum over the family's kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                    "from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --eager --steps 2 "
+                    f"--warmup 1 --no-cpu-baseline --no-block-calib` (profiles/{tag}_pmc_*.csv); bench.py divides by the family's "
+                    "launches per step")
+    json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+    print(json.dumps(t, indent=1))
+
+
+if __name__ == "__main__":
+    main()
