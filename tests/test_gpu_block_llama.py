@@ -136,6 +136,24 @@ def test_fused_let_step_equals_unfused_step(kind):
         assert rel_err(g1[n].cpu(), g0[n].cpu()) <= 1e-4, (n, rel_err(g1[n].cpu(), g0[n].cpu()))
 
 
+def test_fused_adamw_option_trains_close_to_the_default():
+    """CalibConfig.fused_adamw only changes the optimizer's arithmetic in the last bits: the first loss is identical
+    and the run stays within the block's usual rounding amplification of the default run."""
+    import dataclasses
+    d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+    m = d["meta"]
+    act_scales = {f"{PREFIX}.{n}": d[f"act_scale_{n}"] for n in LET_SITES}
+    runs = {}
+    for fused in (False, True):
+        q = build(d)
+        cfg = dataclasses.replace(config(m), fused_adamw=fused)
+        runs[fused] = calibrate_layer(q, d["inps"].clone().to(DEV), d["inps"].clone().to(DEV), d["mask"].to(DEV), cfg, act_scales, {},
+                                      PREFIX, is_llama=True)
+    a, b = torch.tensor(runs[False]["losses"]), torch.tensor(runs[True]["losses"])
+    assert a[0] == b[0]
+    assert torch.allclose(a, b, rtol=3e-2), (a, b)
+
+
 def test_aug_loss_and_resume():
     """aug_loss adds the MSE against the fp block applied to the quantized model's inputs: for a first
     layer both inputs coincide, so the first loss doubles exactly.  resume_state reloads learned

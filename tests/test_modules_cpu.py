@@ -173,3 +173,17 @@ def test_reference_act_scale_shift_files_feed_let_init():
                      "fc1_smooth_scale", "fc1_smooth_shift"}
     assert torch.equal(q.fc1_smooth_shift.detach(), shifts["model.decoder.layers.3.fc1"])
     assert bool((q.qkv_smooth_scale > 0).all()) and bool(torch.isfinite(q.out_smooth_scale).all())
+
+
+def test_grad_norm_matches_the_reference_formula():
+    """Norm of per-parameter norms (reference utils.py:11-24), also when some parameters have no gradient."""
+    import torch
+    from miq.calibrate import grad_norm
+
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(n, generator=g)) for n in (7, 64, 1, 300)]
+    for p in ps[:3]:
+        p.grad = torch.randn(p.shape, generator=g)
+    ref = torch.norm(torch.stack([torch.norm(p.grad.detach(), 2.0) for p in ps if p.grad is not None]), 2.0)
+    assert torch.allclose(grad_norm(ps), ref, rtol=1e-6)
+    assert float(grad_norm([ps[3]])) == 0.0
