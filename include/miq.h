@@ -280,6 +280,23 @@ int miq_masked_softmax_fwd(const void* x, const void* mask, void* out, int64_t R
 int miq_masked_softmax_bwd(const void* p, const void* grad_out, void* dx, int64_t R, int64_t C, float div, int dtype,
                            void* stream);
 
+/*
+ * OmniLlamaRMSNorm (quantize/omni_norm.py:60-71), the norm in front of the quantized q/k/v and up/gate
+ * projections of the Llama block, in one pass per direction:
+ *   rstd = rsqrt(mean(x.float()^2, -1) + eps);  out = (weight * (x * rstd) [+ bias]).to(x dtype)
+ * x, out: [R, C] fp32 or fp16; weight, bias (may be NULL): fp32 [C] (the caller converts fp16 vectors, which is
+ * what type promotion does in the reference); rstd_out: fp32 [R] saved for the backward, may be NULL.
+ * C a multiple of 4.
+ * Backward: dx = rstd * (g*w - u * mean(g*w*u)) with u = x*rstd; d_weight[c] = sum_r g*u, d_bias[c] = sum_r g
+ * (fp32 [C]).  dx, d_weight, d_bias may each be NULL; workspace: miq_rmsnorm_workspace(R, C) floats, needed
+ * when d_weight or d_bias is asked for.
+ */
+int64_t miq_rmsnorm_workspace(int64_t R, int64_t C);
+int miq_rmsnorm_fwd(const void* x, const float* weight, const float* bias, void* out, float* rstd_out, int64_t R,
+                    int64_t C, float eps, int dtype, void* stream);
+int miq_rmsnorm_bwd(const void* grad_out, const void* x, const float* weight, const float* rstd, void* dx,
+                    float* d_weight, float* d_bias, float* workspace, int64_t R, int64_t C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

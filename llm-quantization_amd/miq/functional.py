@@ -486,6 +486,57 @@ class MaskedSoftmax(torch.autograd.Function):
         return dx, None, None
 
 
+def rmsnorm_supported(x, weight, bias) -> bool:
+    C = x.shape[-1]
+    ok = x.is_cuda and x.dtype in (torch.float16, torch.float32) and C % 4 == 0 and 0 < C <= 16384 and x.numel() > 0
+    for t in (weight, bias):
+        ok = ok and (t is None or (t.is_cuda and t.dtype in (torch.float16, torch.float32) and t.numel() == C))
+    return bool(ok and weight is not None)
+
+
+class RMSNorm(torch.autograd.Function):
+    """(weight * (x * rsqrt(mean(x.float()^2, -1) + eps)) [+ bias]).to(x.dtype) with fp32 weight / bias vectors
+    (miq_rmsnorm_fwd / _bwd); the caller converts fp16 vectors with .float() so autograd casts their gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        w = weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        dev = L.check_gpu(x, w, b)
+        C = x.shape[-1]
+        R = x.numel() // C
+        out = torch.empty_like(x)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.call("miq_rmsnorm_fwd", L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), L.ptr(rstd), L.i64(R), L.i64(C),
+                   L.f32(float(eps)), L.i32(L.dtype_code(x)), L.stream_of(x))
+        ctx.save_for_backward(x, w, rstd)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        C = x.shape[-1]
+        R = x.numel() // C
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty(C, dtype=torch.float32, device=x.device) if need_w else None
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if need_b else None
+        ws = None
+        if need_w or need_b:
+            ws = torch.empty(int(L.lib().miq_rmsnorm_workspace(L.i64(R), L.i64(C))), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.call("miq_rmsnorm_bwd", L.ptr(gy), L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws),
+                   L.i64(R), L.i64(C), L.i32(L.dtype_code(x)), L.stream_of(x))
+        return dx, dw, db, None
+
+
 class ActEvalFQ(torch.autograd.Function):
     """Frozen per-channel scales: out = fq(x); dx = g * [level inside the grid]."""
 

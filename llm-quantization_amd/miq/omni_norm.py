@@ -67,17 +67,22 @@ class OmniLlamaRMSNorm(nn.Module):
         self.bias = None
         self.variance_epsilon = eps
         self.use_temporary_parameter = False
+        self.fused = True  # one kernel per direction instead of the elementwise chain below
 
     def forward(self, hidden_states):
-        input_dtype = hidden_states.dtype
-        variance = hidden_states.to(torch.float32).pow(2).mean(-1, keepdim=True)
-        hidden_states = hidden_states * torch.rsqrt(variance + self.variance_epsilon)
         if self.use_temporary_parameter:
             weight = self.temp_weight
             bias = self.temp_bias
         else:
             weight = self.weight
             bias = self.bias if hasattr(self, "bias") else None
+        if self.fused and F.rmsnorm_supported(hidden_states, weight, bias):
+            # every intermediate of the chain below is an fp32 tensor (type promotion), so fp16 vectors enter as fp32
+            return F.RMSNorm.apply(hidden_states, weight.float(), None if bias is None else bias.float(),
+                                   self.variance_epsilon)
+        input_dtype = hidden_states.dtype
+        variance = hidden_states.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        hidden_states = hidden_states * torch.rsqrt(variance + self.variance_epsilon)
         if bias is not None:
             return (weight * hidden_states + bias).to(input_dtype)
         return (weight * hidden_states).to(input_dtype)
