@@ -297,6 +297,15 @@ int miq_rmsnorm_fwd(const void* x, const float* weight, const float* bias, void*
 int miq_rmsnorm_bwd(const void* grad_out, const void* x, const float* weight, const float* rstd, void* dx,
                     float* d_weight, float* d_bias, float* workspace, int64_t R, int64_t C, int dtype, void* stream);
 
+/*
+ * Column sums out[c] = sum_r x[r, c] (fp32 [C]) of a row-major [R, C] fp32 / fp16 matrix: the bias gradient of the
+ * F.linear inside QuantLinear.forward (quantize/int_linear.py:86), which autograd computes with a reduction over
+ * the slow dimension.  workspace: miq_col_sum_workspace(R, C) floats (may be NULL when that is <= C, i.e. one row
+ * chunk).  Deterministic summation order.
+ */
+int64_t miq_col_sum_workspace(int64_t R, int64_t C);
+int miq_col_sum(const void* x, float* out, float* workspace, int64_t R, int64_t C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ def lib() -> ctypes.CDLL:
         _lib.miq_act_workspace.restype = ctypes.c_int64
         _lib.miq_let_workspace.restype = ctypes.c_int64
         _lib.miq_rmsnorm_workspace.restype = ctypes.c_int64
+        _lib.miq_col_sum_workspace.restype = ctypes.c_int64
     return _lib
 
 

@@ -537,6 +537,61 @@ class RMSNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def col_sum(x2d):
+    """fp32 [C] column sums of a contiguous [R, C] fp32 / fp16 matrix (miq_col_sum)."""
+    dev = L.check_gpu(x2d)
+    R, C = x2d.shape
+    out = torch.empty(C, dtype=torch.float32, device=dev)
+    n = int(L.lib().miq_col_sum_workspace(L.i64(R), L.i64(C)))
+    ws = torch.empty(n, dtype=torch.float32, device=dev) if n > C else None
+    with torch.cuda.device(dev):
+        L.call("miq_col_sum", L.ptr(x2d), L.ptr(out), L.ptr(ws), L.i64(R), L.i64(C), L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
+    return out
+
+
+def linear_supported(x, weight, bias) -> bool:
+    ok = bias is not None and x.is_cuda and weight.is_cuda and bias.is_cuda and weight.dim() == 2 and x.dim() >= 2
+    ok = ok and all(t.dtype in (torch.float16, torch.float32) for t in (x, weight, bias))
+    ok = ok and (torch.is_autocast_enabled() or x.dtype == weight.dtype == bias.dtype) and x.numel() > 0
+    return bool(ok)
+
+
+class LinearBias(torch.autograd.Function):
+    """torch.nn.functional.linear(x, weight, bias) with the same GEMMs forward and backward; only the bias gradient
+    differs: one streaming column-sum kernel (miq_col_sum) instead of ATen's reduction over the slow dimension.
+    Under autocast the operands are cast to the autocast dtype first, like the autocast rule of linear."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            x, weight, bias = x.to(dt), weight.to(dt), bias.to(dt)
+        with torch.autocast("cuda", enabled=False):
+            y = torch.nn.functional.linear(x, weight, bias)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad
+        g2 = g.reshape(-1, w.shape[0])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        dx = dw = db = None
+        with torch.autocast("cuda", enabled=False):
+            if need_x:
+                dx = g2.mm(w).reshape(x.shape).to(ctx.in_dtypes[0])
+            if need_w:
+                dw = g2.t().mm(x.reshape(-1, x.shape[-1])).to(ctx.in_dtypes[1])
+            if need_b:
+                # rounded to the compute dtype first, like the reduction it replaces: an fp16 sum that overflows must
+                # become inf so that the loss scaler skips the step exactly when it would with F.linear
+                db = col_sum(g2).to(g2.dtype).to(ctx.in_dtypes[2])
+        return dx, dw, db
+
+
 class ActEvalFQ(torch.autograd.Function):
     """Frozen per-channel scales: out = fq(x); dx = g * [level inside the grid]."""
 

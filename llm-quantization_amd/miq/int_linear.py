@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from . import functional as F
 from .quantizer import UniformAffineQuantizer
 from .quantizer_exp_v2 import ExpAffineQuantizer
 from .quantizer_mix import MixAffineQuantizer
@@ -57,6 +58,7 @@ class QuantLinear(nn.Module):
             self.act_quantizer = None
         self.disable_input_quant = disable_input_quant
         self.use_temporary_parameter = False
+        self.fused_bias_grad = True  # bias gradient by the column-sum kernel when the bias is being trained
 
     def forward(self, input: torch.Tensor):
         if self.use_temporary_parameter:
@@ -70,6 +72,9 @@ class QuantLinear(nn.Module):
             bias = self.bias
         if self.use_act_quant and not self.disable_input_quant:
             input = self.act_quantizer(input)
+        if (self.fused_bias_grad and bias is not None and bias.requires_grad and torch.is_grad_enabled()
+                and self.fwd_func is TF.linear and not self.fwd_kwargs and F.linear_supported(input, weight, bias)):
+            return F.LinearBias.apply(input, weight, bias)
         return self.fwd_func(input, weight, bias, **self.fwd_kwargs)
 
     def set_ic_cluster_counts(self, counts, w_dim=1, a_dim=2):
