@@ -306,6 +306,21 @@ int miq_rmsnorm_bwd(const void* grad_out, const void* x, const float* weight, co
 int64_t miq_col_sum_workspace(int64_t R, int64_t C);
 int miq_col_sum(const void* x, float* out, float* workspace, int64_t R, int64_t C, int dtype, void* stream);
 
+/*
+ * Rotary position embedding of the Llama query / key states in front of the q.k^T quantizers
+ * (models/int_llama_layer.py:124-125, transformers' apply_rotary_pos_emb):
+ *   out = x * cos + rotate_half(x) * sin,  rotate_half(x) = cat(-x[..., D/2:], x[..., :D/2])
+ * for a logical [B, H, T, D] tensor given by element strides (last stride 1), so the transposed view of the
+ * projection output is read in place and `out` can be written contiguous; cos / sin: [table batches, T, D] of the
+ * same dtype (table_batch_stride = 0 shares one table).  Every product and the sum are rounded to the dtype like
+ * PyTorch's intermediates (bit-exact).  backward != 0 applies the transposed rotation to a gradient:
+ *   out_lo = x_lo cos_lo + x_hi sin_hi,  out_hi = x_hi cos_hi - x_lo sin_lo.
+ * D a multiple of 8 (fp32) or 16 (fp16); strides multiples of 4 / 8 elements.
+ */
+int miq_rotary(const void* x, const void* cos, const void* sin, void* out, int64_t B, int64_t H, int64_t T, int64_t D,
+               int64_t xs_b, int64_t xs_h, int64_t xs_t, int64_t os_b, int64_t os_h, int64_t os_t,
+               int64_t table_batch_stride, int backward, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

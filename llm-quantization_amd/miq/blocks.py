@@ -365,6 +365,8 @@ class _Rotary(nn.Module):
     """Rotary position embedding in the Hugging Face Llama layout (the two halves of a head are the
     real / imaginary parts).  cos/sin tables are built once per (length, device, dtype)."""
 
+    fused = True  # one kernel per tensor and direction instead of the elementwise chain (class-wide switch)
+
     def __init__(self, head_dim: int, theta: float = 10000.0):
         super().__init__()
         self.head_dim, self.theta = head_dim, theta
@@ -381,6 +383,8 @@ class _Rotary(nn.Module):
 
     def forward(self, q, k, position_ids):
         cos, sin = self.tables(position_ids, q.device, q.dtype)
+        if self.fused and k.dtype == q.dtype and F.rotary_supported(q, cos, sin) and F.rotary_supported(k, cos, sin):
+            return F.RotaryEmb.apply(q, cos, sin), F.RotaryEmb.apply(k, cos, sin)
         return q * cos + _rotate_half(q) * sin, k * cos + _rotate_half(k) * sin
 
 

@@ -537,6 +537,52 @@ class RMSNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def rotary_supported(x, cos, sin) -> bool:
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.float32) and x.numel() > 0):
+        return False
+    vec = 8 if x.dtype == torch.float16 else 4
+    B, H, T, D = x.shape
+    ok = D % (2 * vec) == 0 and x.stride(3) == 1 and all(s % vec == 0 and s >= 0 for s in x.stride()[:3])
+    ok = ok and x.data_ptr() % 16 == 0
+    for t in (cos, sin):
+        ok = ok and t.is_cuda and t.dtype == x.dtype and t.dim() == 4 and t.is_contiguous()
+        ok = ok and t.shape[1] == 1 and t.shape[0] in (1, B) and tuple(t.shape[2:]) == (T, D)
+    return bool(ok)
+
+
+def _rotary_call(x, cos, sin, out, backward: bool):
+    B, H, T, D = x.shape
+    tab_bs = T * D if cos.shape[0] > 1 else 0
+    with torch.cuda.device(x.device):
+        L.call("miq_rotary", L.ptr(x), L.ptr(cos), L.ptr(sin), L.ptr(out), L.i64(B), L.i64(H), L.i64(T), L.i64(D),
+               L.i64(x.stride(0)), L.i64(x.stride(1)), L.i64(x.stride(2)), L.i64(out.stride(0)), L.i64(out.stride(1)),
+               L.i64(out.stride(2)), L.i64(tab_bs), L.i32(int(backward)), L.i32(L.dtype_code(x)), L.stream_of(x))
+
+
+class RotaryEmb(torch.autograd.Function):
+    """x * cos + rotate_half(x) * sin for a [B, H, T, D] tensor (any strides with a dense last dimension, e.g. the
+    transposed view of a projection output) and [B or 1, 1, T, D] tables; the result is contiguous.  The gradient
+    comes back in the [B, T, H, D] memory layout of a projection output (as a transposed view), so the view /
+    transpose backward in front of the linear needs no copy."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        _rotary_call(x, cos, sin, out, False)
+        ctx.save_for_backward(cos, sin)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, sin = ctx.saved_tensors
+        if not rotary_supported(g, cos, sin):
+            g = g.contiguous()
+        B, H, T, D = g.shape
+        dx = torch.empty((B, T, H, D), dtype=g.dtype, device=g.device).transpose(1, 2)
+        _rotary_call(g, cos, sin, dx, True)
+        return dx, None, None
+
+
 def col_sum(x2d):
     """fp32 [C] column sums of a contiguous [R, C] fp32 / fp16 matrix (miq_col_sum)."""
     dev = L.check_gpu(x2d)

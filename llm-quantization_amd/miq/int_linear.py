@@ -17,6 +17,8 @@ from .quantizer_mix_v2 import Mix2AffineQuantizer
 
 
 class QuantLinear(nn.Module):
+    fused_bias_grad = True  # bias gradient by the column-sum kernel when the bias is being trained (class-wide switch)
+
     def __init__(
         self,
         org_module: nn.Linear,
@@ -58,7 +60,6 @@ class QuantLinear(nn.Module):
             self.act_quantizer = None
         self.disable_input_quant = disable_input_quant
         self.use_temporary_parameter = False
-        self.fused_bias_grad = True  # bias gradient by the column-sum kernel when the bias is being trained
 
     def forward(self, input: torch.Tensor):
         if self.use_temporary_parameter:

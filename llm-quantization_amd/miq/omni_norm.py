@@ -61,13 +61,14 @@ class OmniLayerNorm(nn.Module):
 
 
 class OmniLlamaRMSNorm(nn.Module):
+    fused = True  # one kernel per direction instead of the elementwise chain in forward (class-wide switch)
+
     def __init__(self, ori_norm, eps=1e-6):
         super().__init__()
         self.register_buffer("weight", ori_norm.weight)
         self.bias = None
         self.variance_epsilon = eps
         self.use_temporary_parameter = False
-        self.fused = True  # one kernel per direction instead of the elementwise chain below
 
     def forward(self, hidden_states):
         if self.use_temporary_parameter:
