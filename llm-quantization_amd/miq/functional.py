@@ -657,6 +657,22 @@ class ActEvalFQ(torch.autograd.Function):
         return dx.reshape(g.shape), None, None, None
 
 
+TENSOR_FOLD = True  # module-wide switch of _tensor_fold (A/B timing)
+
+
+def _tensor_fold(R: int, C: int, layout) -> int:
+    """Per-tensor statistics do not depend on how the elements are cut into rows: a narrow [R, C] slab (the
+    [.., head_dim] operands of the attention matmuls) is handed to the column kernels as [R / k, C * k], so that
+    every lane of their 64-lane x 16-byte tiles has a channel pack to work on (C = 128 fp16 fills 16 of 64 lanes:
+    measured 66 us instead of 32 us for 8.4 M elements).  Returns k (1 = leave as is)."""
+    if not TENSOR_FOLD or layout.n_clusters != 1 or layout.covered != C or C >= 2048 or C % 8:
+        return 1
+    k = 1
+    while C * k * 2 <= 4096 and R % (k * 2) == 0:
+        k *= 2
+    return k
+
+
 class ActCalibFQ(torch.autograd.Function):
     """Calibration-mode forward with freshly computed statistics (no cached values): the scale is a
     function of x, so the backward routes the scale gradient to the extreme elements."""
@@ -664,18 +680,28 @@ class ActCalibFQ(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_bits, metric, layout, cached_min, cached_max, holder, dp=None):
         x = x.contiguous()
-        x2 = x.reshape(-1, x.shape[-1])
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        k = _tensor_fold(x2.shape[0], C, layout) if x2.numel() else 1
+        if k > 1:
+            x2 = x2.reshape(-1, C * k)
+            layout = ClusterLayout.get(None, C * k, x.device)
+            if cached_min is not None:  # one cluster: all entries are equal
+                cached_min = cached_min[:1].expand(C * k).contiguous()
+                cached_max = cached_max[:1].expand(C * k).contiguous()
         ctx.dp = dp
         if dp is not None and dp.active and dp.sync_stats:
             st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max, dp=dp)
             out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
         else:
             out, _, st = act_calib_quant_fwd(x2, n_bits, metric, layout, cached_min, cached_max)
-        holder.update(st)
         ctx.fresh = cached_min is None
         ctx.layout = layout
         ctx.n_bits = n_bits
         ctx.save_for_backward(x2, st["scale"], st["rzp"], st["chan_min"], st["chan_max"], st["cmin"], st["cmax"])
+        if k > 1:  # publish vectors of the caller's channel count
+            st = {n: (v if n.startswith("chan_") else v[:C]) for n, v in st.items()}
+        holder.update(st)
         return out.reshape(x.shape)
 
     @staticmethod

@@ -139,3 +139,29 @@ def test_backward_with_non_finite_activations(dt, bad):
     ok = torch.isfinite(ref_dx)
     z = torch.zeros_like(ref_dx)
     assert rel_err(torch.where(ok, dx, z), torch.where(ok, ref_dx, z)) <= (5e-3 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_narrow_per_tensor_slabs_are_folded_without_changing_the_result(dt):
+    """[.., head_dim] operands with per-tensor statistics run through the column kernels as wide rows: the
+    quantized values are the same bit for bit, the gradient equal up to the summation order of the scale term."""
+    dt = DT[dt]
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = (torch.randn(2, 4, 96, 128, generator=g, device=DEV) * 2).to(dt)
+    go = torch.randn(x.shape, generator=g, device=DEV).to(dt)
+    layout = F.ClusterLayout.get(None, 128, DEV)
+    assert F._tensor_fold(2 * 4 * 96, 128, layout) == 32
+    assert F._tensor_fold(2 * 4 * 96, 128, F.ClusterLayout.get([64, 64], 128, DEV)) == 1
+    assert F._tensor_fold(7, 128, layout) == 1 and F._tensor_fold(6, 128, layout) == 2
+    x2 = x.reshape(-1, 128)
+    ref_out, _, ref_st = F.act_calib_quant_fwd(x2, 4, "minmax", layout)
+    ref_dx = F.colquant_bwd(go.reshape(-1, 128), x2, ref_st["scale"], ref_st["rzp"], 4,
+                            route=(ref_st["chan_min"], ref_st["chan_max"], ref_st["cmin"], ref_st["cmax"], layout))
+    leaf = x.clone().requires_grad_(True)
+    holder = {}
+    out = F.ActCalibFQ.apply(leaf, 4, "minmax", layout, None, None, holder, None)
+    assert torch.equal(out.reshape(-1, 128), ref_out)
+    for name in ("scale", "zp", "rzp", "cmin", "cmax"):
+        assert holder[name].shape == (128,) and torch.equal(holder[name], ref_st[name])
+    (dx,) = torch.autograd.grad(out, leaf, go)
+    assert rel_err(dx.reshape(-1, 128), ref_dx) <= (2e-3 if dt == torch.float16 else 1e-5)
