@@ -87,6 +87,18 @@ __device__ __forceinline__ float let_apply(float w, float cs, bool has_cs, float
     if (has_r) t = rdiv ? t / r : t * r;
     return t;
 }
+// The same for the backward kernels, with the corrected reciprocal product x * rr, rr = 1 / r, in place of the
+// division (UncheckedDivisor: the IEEE quotient for every finite operand pair away from the ends of the exponent
+// range).  Both backward kernels use this one function, so they agree on t bit for bit.
+__device__ __forceinline__ float quot(float x, float d, float rd) {
+    const float q0 = x * rd;
+    return __builtin_fmaf(__builtin_fmaf(-q0, d, x), rd, q0);
+}
+__device__ __forceinline__ float let_apply_bwd(float w, float cs, bool has_cs, float r, float rr, bool has_r, bool rdiv) {
+    float t = has_cs ? w * cs : w;
+    if (has_r) t = rdiv ? quot(t, r, rr) : t * r;
+    return t;
+}
 
 template <typename TO, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
@@ -161,7 +173,7 @@ k_let_fwd(LetArgs a, TO* __restrict__ out, float* __restrict__ scale_out, float*
 // A register-resident single pass (rows strided over persistent teams, column sums in registers) was
 // measured at 1.2 TB/s: three dependent team reductions per row with only two rows in flight per CU.
 struct RowCtx {
-    float s, rzp, rmax, rmin, share_max, share_min, pad0, pad1;
+    float s, rzp, rmax, rmin, share_max, share_min, inv_s, inv_r;  // inv_*: 1 / s and 1 / rs[row]
 };
 
 template <typename TG, int TEAM, int NV>
@@ -180,6 +192,7 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
     w.load(a.w + row * a.I, a.I, lane);
     g.load(gout + row * a.I, a.I, lane);
     const float r = has_r ? a.rs[row] : 1.f;
+    const float rr = 1.0f / r;
     // w.v <- t (the column factors are read once per element: the row kernel touches each once)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -188,12 +201,13 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
         if (has_cs) c4 = *reinterpret_cast<const float4*>(a.cs + w.offset(k));
         const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w.v[k].e[e] = let_apply(w.v[k].e[e], cv[e], has_cs, r, has_r, rdiv);
+        for (int e = 0; e < 4; ++e) w.v[k].e[e] = let_apply_bwd(w.v[k].e[e], cv[e], has_cs, r, rr, has_r, rdiv);
     }
     (void)npack;
     float rmin, rmax;
     row_minmax(w, false, lds, rmin, rmax);
     const LetCtx c = let_ctx(a, row, rmin, rmax);
+    const float inv_s = 1.0f / c.s;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};  // dS, #t == rmax, #t == rmin, sum of m*g*t (straight-through part of d_rs)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -202,7 +216,7 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
         for (int e = 0; e < 4; ++e) {
             const float t = w.v[k].e[e];
             const float gv = to_f<TG>(g.v[k].e[e]);
-            const float q = t / c.s;
+            const float q = quot(t, c.s, inv_s);
             const float xi = rint_ste(q) + c.rzp;
             const bool m = (xi >= 0.f) && (xi <= c.qmax);
             const float xd = clampf(xi, 0.f, c.qmax) - c.rzp;
@@ -242,7 +256,8 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
         o.s = c.s; o.rzp = c.rzp; o.rmax = rmax; o.rmin = rmin;
         o.share_max = tot_max / acc[1];
         o.share_min = tot_min / acc[2];
-        o.pad0 = o.pad1 = 0.f;
+        o.inv_s = inv_s;
+        o.inv_r = rr;
         rowctx[row] = o;
     }
 }
@@ -275,12 +290,12 @@ k_let_bwd_cols(LetArgs a, const TG* __restrict__ gout, const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float wv_ = w.e[e];
-                const float t = let_apply(wv_, cv[e], has_cs, r, has_r, rdiv);
-                const float xi = rint_ste(t / c.s) + c.rzp;
+                const float t = let_apply_bwd(wv_, cv[e], has_cs, r, c.inv_r, has_r, rdiv);
+                const float xi = rint_ste(quot(t, c.s, c.inv_s)) + c.rzp;
                 float dt = ((xi >= 0.f) && (xi <= qmax)) ? to_f<TG>(g.e[e]) : 0.f;
                 if (t == c.rmax) dt += c.share_max;
                 if (t == c.rmin) dt += c.share_min;
-                const float d_t1 = has_r ? (rdiv ? dt / r : dt * r) : dt;
+                const float d_t1 = has_r ? (rdiv ? quot(dt, r, c.inv_r) : dt * r) : dt;
                 acs[e] += d_t1 * wv_;
                 ash[e] += wv_ * gs;
             }
