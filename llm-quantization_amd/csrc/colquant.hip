@@ -102,11 +102,13 @@ struct ScaleArgs {
 };
 
 // step 1: fold the row-chunk partials of every output channel's source column and apply the
-// running-min/max or EMA update against the cached statistics.  Block = 64 channels x 4 waves; wave w
-// folds chunks w, w+4, ... (coalesced 256-byte reads, several in flight), LDS joins the four waves.
+// running-min/max or EMA update against the cached statistics.  Block = 64 channels x 16 waves; wave w
+// folds chunks w, w+16, ... (coalesced 256-byte reads, eight in flight): with the ~128 chunks of a
+// [2048, 4096] slab that is one round of loads per wave instead of eight dependent ones.  LDS joins the waves.
+constexpr int kCombineWaves = 16;
 template <typename T>
-__global__ void __launch_bounds__(256) k_colstat_combine(ScaleArgs<T> a) {
-    __shared__ float smn[4][64], smx[4][64];
+__global__ void __launch_bounds__(64 * kCombineWaves) k_colstat_combine(ScaleArgs<T> a) {
+    __shared__ float smn[kCombineWaves][64], smx[kCombineWaves][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool valid = c < a.C;
@@ -114,15 +116,15 @@ __global__ void __launch_bounds__(256) k_colstat_combine(ScaleArgs<T> a) {
     if (valid) {
         const int src = a.idx ? a.idx[c] : c;
         int j = w;
-        for (; j + 12 < a.nchunk; j += 16) {
+        for (; j + 3 * kCombineWaves < a.nchunk; j += 4 * kCombineWaves) {
             const float a0 = a.pmin[(long long)j * a.C + src], b0 = a.pmax[(long long)j * a.C + src];
-            const float a1 = a.pmin[(long long)(j + 4) * a.C + src], b1 = a.pmax[(long long)(j + 4) * a.C + src];
-            const float a2 = a.pmin[(long long)(j + 8) * a.C + src], b2 = a.pmax[(long long)(j + 8) * a.C + src];
-            const float a3 = a.pmin[(long long)(j + 12) * a.C + src], b3 = a.pmax[(long long)(j + 12) * a.C + src];
+            const float a1 = a.pmin[(long long)(j + kCombineWaves) * a.C + src], b1 = a.pmax[(long long)(j + kCombineWaves) * a.C + src];
+            const float a2 = a.pmin[(long long)(j + 2 * kCombineWaves) * a.C + src], b2 = a.pmax[(long long)(j + 2 * kCombineWaves) * a.C + src];
+            const float a3 = a.pmin[(long long)(j + 3 * kCombineWaves) * a.C + src], b3 = a.pmax[(long long)(j + 3 * kCombineWaves) * a.C + src];
             mn = nmin(nmin(mn, a0), nmin(a1, nmin(a2, a3)));
             mx = nmax(nmax(mx, b0), nmax(b1, nmax(b2, b3)));
         }
-        for (; j < a.nchunk; j += 4) {
+        for (; j < a.nchunk; j += kCombineWaves) {
             mn = nmin(mn, a.pmin[(long long)j * a.C + src]);
             mx = nmax(mx, a.pmax[(long long)j * a.C + src]);
         }
@@ -131,8 +133,11 @@ __global__ void __launch_bounds__(256) k_colstat_combine(ScaleArgs<T> a) {
     smx[w][lane] = mx;
     __syncthreads();
     if (w != 0 || !valid) return;
-    mn = nmin(nmin(smn[0][lane], smn[1][lane]), nmin(smn[2][lane], smn[3][lane]));
-    mx = nmax(nmax(smx[0][lane], smx[1][lane]), nmax(smx[2][lane], smx[3][lane]));
+#pragma unroll
+    for (int u = 1; u < kCombineWaves; ++u) {
+        mn = nmin(mn, smn[u][lane]);
+        mx = nmax(mx, smx[u][lane]);
+    }
     if (a.cached_min) {
         const float pm = to_f<T>(a.cached_min[c]), px = to_f<T>(a.cached_max[c]);
         if (a.metric == 0) {
@@ -147,7 +152,10 @@ __global__ void __launch_bounds__(256) k_colstat_combine(ScaleArgs<T> a) {
     a.pmax[(long long)a.nchunk * a.C + c] = mx;
 }
 
-// step 2: one block per cluster (plus one block for channels that belong to no cluster)
+// step 2: gridDim.y blocks per cluster (plus as many for the channels that belong to no cluster).  Every block
+// of a cluster reduces the whole cluster (its per-channel statistics sit in L2; four loads in flight) and writes
+// the parameters of its own slice of channels, so that a single large cluster (per-tensor statistics: all C
+// channels) is not one block walking the channels 256 at a time.
 template <typename T>
 __global__ void __launch_bounds__(256) k_cluster_scale(ScaleArgs<T> a) {
     __shared__ float lds[32];
@@ -159,15 +167,22 @@ __global__ void __launch_bounds__(256) k_cluster_scale(ScaleArgs<T> a) {
     const float* cmx = a.pmax + (long long)a.nchunk * a.C;
     float mm[2] = {__builtin_inff(), -__builtin_inff()};
     if (!own) {
-        for (int c = st + threadIdx.x; c < en; c += 256) {
-            mm[0] = nmin(mm[0], cmn[c]);
-            mm[1] = nmax(mm[1], cmx[c]);
+        for (int c = st + threadIdx.x; c < en; c += 1024) {
+            float vn[4], vx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = c + 256 * u;
+                vn[u] = cc < en ? cmn[cc] : __builtin_inff();
+                vx[u] = cc < en ? cmx[cc] : -__builtin_inff();
+            }
+            mm[0] = nmin(nmin(mm[0], vn[0]), nmin(vn[1], nmin(vn[2], vn[3])));
+            mm[1] = nmax(nmax(mm[1], vx[0]), nmax(vx[1], nmax(vx[2], vx[3])));
         }
         team_reduce<256, 2>(mm, OpMinMax(), lds);
     }
     const float qmax = exp2f((float)a.n_bits) - 1.0f;
     const float lo = rnd<T>(kClipLo);
-    for (int c = st + threadIdx.x; c < en; c += 256) {
+    for (int c = st + blockIdx.y * 256 + threadIdx.x; c < en; c += 256 * gridDim.y) {
         const float mn = own ? cmn[c] : mm[0];
         const float mx = own ? cmx[c] : mm[1];
         a.cmin_out[c] = from_f<T>(mn);
@@ -389,8 +404,8 @@ static int cluster_scale_t(float* pmin, float* pmax, int nchunk, int64_t C, cons
     a.cmin_out = (T*)cmin_out; a.cmax_out = (T*)cmax_out; a.scale = (T*)scale; a.zp = (T*)zp; a.rzp = (T*)rzp;
     const unsigned grid = (unsigned)(ncl + (covered < C ? 1 : 0));
     if (grid == 0) return 0;
-    hipLaunchKernelGGL((k_colstat_combine<T>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL((k_cluster_scale<T>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((k_colstat_combine<T>), dim3((unsigned)((C + 63) / 64)), dim3(64 * kCombineWaves), 0, stream, a);
+    hipLaunchKernelGGL((k_cluster_scale<T>), dim3(grid, cluster_slices(C, grid)), dim3(256), 0, stream, a);
     MIQ_CHECK_LAUNCH("miq_cluster_scale");
     return 0;
 }

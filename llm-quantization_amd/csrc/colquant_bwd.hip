@@ -196,7 +196,10 @@ k_colbwd_fold(const float* __restrict__ part, float* __restrict__ sums, int nchu
         sums[(long long)k * C + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
-// one block per cluster (+1 for un-clustered channels): per-channel shares for the max / min elements
+// gridDim.y blocks per cluster (and for the un-clustered channels): per-channel shares for the max / min elements.
+// Every block of a cluster sums the whole cluster (L2-resident vectors, four loads in flight, the same fixed order
+// in every block) and writes the shares of its own slice of channels: a single large cluster (per-tensor
+// statistics) is spread over up to 16 blocks instead of one block walking all channels.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__ chan_min,
@@ -209,9 +212,10 @@ k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__
     const int st = own ? starts[ncl] : starts[k];
     const int en = own ? C : starts[k + 1];
     const float lo = rnd<T>(kClipLo);
+    const int first = st + blockIdx.y * 256 + threadIdx.x, step = 256 * gridDim.y;
     auto colsum = [&](int which, int c) { return sums[(long long)which * C + c]; };
     if (own) {
-        for (int c = st + threadIdx.x; c < en; c += 256) {
+        for (int c = first; c < en; c += step) {
             const float mn = to_f<T>(kmin[c]), mx = to_f<T>(kmax[c]);
             const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
             const bool live = s_raw >= lo && s_raw <= kClipHi;
@@ -223,33 +227,45 @@ k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__
     }
     if (en <= st) return;
     const float mn = to_f<T>(kmin[st]), mx = to_f<T>(kmax[st]);  // constant over the cluster
-    // cluster totals: dS, number of channels attaining the cluster max / min.  Each thread keeps its first
-    // channel in registers, so clusters of up to 256 channels need a single round of loads.
-    const int c0 = st + threadIdx.x;
-    const bool has0 = c0 < en;
-    float ds0 = 0.f, nmx0 = 1.f, nmn0 = 1.f, cx0 = 0.f, cn0 = 0.f;
+    // this block's first channel: loaded before the reduction so that its shares need no dependent loads afterwards
+    // (clusters of up to 256 channels per slice are written from registers)
+    const bool has0 = first < en;
+    float n1 = 1.f, n2 = 1.f, cx0 = 0.f, cn0 = 0.f;
     if (has0) {
-        ds0 = colsum(0, c0);
-        nmx0 = colsum(1, c0);
-        nmn0 = colsum(2, c0);
-        cx0 = chan_max[c0];
-        cn0 = chan_min[c0];
+        n1 = colsum(1, first);
+        n2 = colsum(2, first);
+        cx0 = chan_max[first];
+        cn0 = chan_min[first];
     }
-    float acc[3] = {ds0, (has0 && cx0 == mx) ? 1.f : 0.f, (has0 && cn0 == mn) ? 1.f : 0.f};
-    for (int c = c0 + 256; c < en; c += 256) {
-        acc[0] += colsum(0, c);
-        acc[1] += (chan_max[c] == mx) ? 1.f : 0.f;
-        acc[2] += (chan_min[c] == mn) ? 1.f : 0.f;
+    // cluster totals: dS, number of channels attaining the cluster max / min
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int c = st + threadIdx.x; c < en; c += 1024) {
+        float ds[4], cx[4], cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cc = c + 256 * u;
+            const bool in = cc < en;
+            ds[u] = in ? colsum(0, cc) : 0.f;
+            cx[u] = in ? chan_max[cc] : 0.f;
+            cn[u] = in ? chan_min[cc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = c + 256 * u < en;
+            acc[0] += ds[u];
+            acc[1] += (in && cx[u] == mx) ? 1.f : 0.f;
+            acc[2] += (in && cn[u] == mn) ? 1.f : 0.f;
+        }
     }
     team_sum<256, 3>(acc, lds);
     const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
     const bool live = s_raw >= lo && s_raw <= kClipHi;
     const float d = live ? acc[0] / qmax : 0.f;
     if (has0) {
-        share_max[c0] = (cx0 == mx) ? (d / acc[1]) / nmx0 : 0.f;
-        share_min[c0] = (cn0 == mn) ? (-d / acc[2]) / nmn0 : 0.f;
+        share_max[first] = (cx0 == mx) ? (d / acc[1]) / n1 : 0.f;
+        share_min[first] = (cn0 == mn) ? (-d / acc[2]) / n2 : 0.f;
     }
-    for (int c = c0 + 256; c < en; c += 256) {
+    for (int c = first + step; c < en; c += step) {
         share_max[c] = (chan_max[c] == mx) ? (d / acc[1]) / colsum(1, c) : 0.f;
         share_min[c] = (chan_min[c] == mn) ? (-d / acc[2]) / colsum(2, c) : 0.f;
     }
@@ -424,7 +440,7 @@ static int colquant_bwd_t(const void* g, const void* x, const void* scale, const
     }
     if (phase != 1) {
         const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
-        hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk), block, 0, stream, sums, (int)C, chan_min, chan_max,
+        hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk, cluster_slices(C, nblk)), block, 0, stream, sums, (int)C, chan_min, chan_max,
                            (const T*)kmin, (const T*)kmax, starts, ncl, qmax, share_min, share_max);
         if (vec_ok)
             hipLaunchKernelGGL((k_colbwd_fixup<T, N>), grid, block, 0, stream, (const T*)x, part, nchunk, chan_min, chan_max,

@@ -435,6 +435,12 @@ constexpr int kRowMaxPacks = 8192;
 
 template <int TEAM> constexpr int block_of() { return TEAM > 256 ? TEAM : 256; }
 
+// blocks per cluster of the per-cluster parameter kernels: enough 256-channel slices for an average cluster, at most 16
+static inline unsigned cluster_slices(long long C, unsigned n_blocks) {
+    const long long per = (C / (n_blocks > 0 ? n_blocks : 1) + 255) / 256;
+    return (unsigned)(per < 1 ? 1 : (per > 16 ? 16 : per));
+}
+
 static inline bool is_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // fills GEO for an [O, I] matrix with optional grouping; returns false when the matrix is too large
