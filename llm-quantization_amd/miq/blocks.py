@@ -138,6 +138,9 @@ class _BlockBase(nn.Module):
         for _n, m in self.quant_linears():
             src = m.temp_weight if hasattr(m, "temp_weight") else m.weight
             q = m.weight_quantizer
+            if self._half_weight_path(q, src):
+                m.temp_weight, _ = q.forward_let(src)
+                continue
             if (type(q) is UniformAffineQuantizer and q.enable and q.n_bits < 16 and q.metric != "fix0to1" and q.dynamic
                     and q.dynamic_method in ("per_token", "per_channel") and not q.group_size and src.is_cuda and src.dim() == 2
                     and src.dtype in (torch.float32, torch.float16) and (not q.lwc or q.upbound_factor.dtype == src.dtype)):
@@ -166,6 +169,19 @@ class _BlockBase(nn.Module):
                 m.temp_bias = m.bias
             m.use_temporary_parameter = True
 
+    half_weights = True  # under fp16 autocast, quantize plain fp32 weights straight into the fp16 tensor the linear uses
+
+    @classmethod
+    def _half_weight_path(cls, q, w) -> bool:
+        """Under fp16 autocast the linear casts its fp32 quantized weight to fp16 (and autograd casts the fp16 weight
+        gradient back): 6 extra bytes per element each way.  The LET-fused kernel without factors is the plain
+        row-wise quantizer with an fp16 store and an fp16 gradient load, so weights that are not themselves functions
+        of trained tensors go through it."""
+        from .quantizer import UniformAffineQuantizer
+        return (cls.half_weights and cls.fused_let and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.float16 and type(q) is UniformAffineQuantizer
+                and not w.requires_grad and w.dtype == torch.float32 and q.let_fusable(w))
+
     fused_let = True  # use the LET-fused weight quantizer kernels when the configuration allows
 
     def _let_fusable(self):
@@ -177,7 +193,7 @@ class _BlockBase(nn.Module):
     def _let_linear(m, cs=None, rs=None, rs_div=True, shift=None):
         """temp_weight / temp_bias of one linear: quantize((W * cs) / rs or * rs); bias + W @ shift.
         The caller applies the row factor and the output shift to the bias (small vectors)."""
-        if cs is None and rs is None and shift is None:
+        if cs is None and rs is None and shift is None and not _BlockBase._half_weight_path(m.weight_quantizer, m.weight):
             wq, wshift = m.weight_quantizer(m.weight), None  # nothing to fuse: the plain row kernels are leaner
         else:
             wq, wshift = m.weight_quantizer.forward_let(m.weight, cs, rs, rs_div, shift)

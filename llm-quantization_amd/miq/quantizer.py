@@ -157,7 +157,7 @@ class UniformAffineQuantizer(nn.Module):
         as forward() on the materialised tensor; gradients reach cs, rs, shift and the LWC factors."""
         up, low = self._lwc_params(w)
         # under autocast the consuming linear casts the weight to fp16: let the kernel store that directly
-        half_out = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16
+        half_out = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16
         out, wshift, scale, rzp = F.LetRowFQ.apply(w, cs, rs, bool(rs_div), shift, up, low, self.n_bits, bool(self.symmetric),
                                                    half_out)
         self.scale = scale

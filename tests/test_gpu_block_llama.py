@@ -207,3 +207,47 @@ def test_layer_loop_two_blocks_saves_and_resumes(tmp_path):
                                   is_llama=True, resume={0: {k: v.float() for k, v in stored[0].items()}})
     for k in d["omni_keys"]:
         assert torch.equal(p2[0][k].cpu(), stored[0][k].cpu()), k
+
+
+@pytest.mark.parametrize("let", [True, False])
+def test_half_weight_path_under_autocast_equals_quantize_then_cast(let):
+    """Under fp16 autocast plain fp32 weights are quantized straight into the fp16 tensor the linear uses: the
+    temporary weights equal the cast of the fp32 quantized weights bit for bit, so the block output is unchanged,
+    and the LWC gradients agree with the cast path to fp16 rounding of the weight gradient."""
+    from miq.blocks import _BlockBase
+    from miq.int_linear import QuantLinear
+    d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+    m = d["meta"]
+    cfg = config(m)
+    act_scales = {f"{PREFIX}.{n}": d[f"act_scale_{n}"] for n in LET_SITES}
+    x = d["inps"][:1].to(DEV).half()
+    mask = d["mask"].to(DEV).half()
+    results = []
+    try:
+        for half in (True, False):
+            _BlockBase.half_weights = half
+            q = build(d)
+            q.set_quant_state(weight_quant=False, act_quant=True)
+            q.let = let
+            if let:
+                init_let(q, act_scales, {}, PREFIX, cfg, None, torch.float32, torch.device(DEV), is_llama=True)
+            q.float()
+            with torch.autocast("cuda", dtype=torch.float16):
+                q.smooth_and_quant_temporary()
+                out = q(x, attention_mask=mask)[0]
+                loss = (out.float() ** 2).mean()
+            lin = {n: mod for n, mod in q.named_modules() if isinstance(mod, QuantLinear)}
+            plain = [n for n in lin if not let or n.endswith("down_proj")]
+            for n in plain:
+                assert lin[n].temp_weight.dtype == (torch.float16 if half else torch.float32), n
+            names = [n for n, _p in q.named_parameters() if "bound_factor" in n]
+            grads = torch.autograd.grad(loss, [dict(q.named_parameters())[n] for n in names])
+            results.append((out.detach(), {n: mod.temp_weight.detach().half() for n, mod in lin.items()}, dict(zip(names, grads))))
+    finally:
+        _BlockBase.half_weights = True
+    (o1, w1, g1), (o0, w0, g0) = results
+    for n in w0:
+        assert torch.equal(w1[n], w0[n]), n
+    assert torch.equal(o1, o0)
+    for n in g0:
+        assert rel_err(g1[n].cpu(), g0[n].cpu()) <= 2e-3, (n, rel_err(g1[n].cpu(), g0[n].cpu()))

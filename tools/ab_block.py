@@ -17,11 +17,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_block  # noqa: E402
 from miq import functional  # noqa: E402
-from miq.blocks import _Rotary  # noqa: E402
+from miq.blocks import _BlockBase, _Rotary  # noqa: E402
 from miq.int_linear import QuantLinear  # noqa: E402
 from miq.omni_norm import OmniLlamaRMSNorm  # noqa: E402
 
-SWITCHES = {"tensor_fold": (functional, "TENSOR_FOLD"), "rotary": (_Rotary, "fused"), "bias_grad": (QuantLinear, "fused_bias_grad"), "rmsnorm": (OmniLlamaRMSNorm, "fused")}
+SWITCHES = {"half_weights": (_BlockBase, "half_weights"), "tensor_fold": (functional, "TENSOR_FOLD"), "rotary": (_Rotary, "fused"), "bias_grad": (QuantLinear, "fused_bias_grad"), "rmsnorm": (OmniLlamaRMSNorm, "fused")}
 
 
 def one_run_ms(model, amp):
