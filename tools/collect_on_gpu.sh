@@ -1,0 +1,31 @@
+#!/bin/bash
+# Collects one measurement directory on the GPU box (run from the repository root):
+#   bash tools/collect_on_gpu.sh gpurun_out/r01_f
+# bench line, kernel trace of the bench, the two PMC passes (own runs, no tracing), operator families, the larger
+# block shapes, and a kernel trace of the Llama-2-7B fp16 calibration step.  Every GPU step has its own time limit
+# and the script stops at the first failure.  tools/collect_profiles.py installs the directory into profiles/.
+set -e -o pipefail
+D=${1:?output directory}
+R=$(pwd)
+mkdir -p "$D"
+D=$(cd "$D" && pwd)
+export TMPDIR=/tmp
+echo "[collect] bench"; timeout -k 10 600 python3 -u bench.py > "$D/bench.json.log" 2> "$D/bench.err"
+cd /tmp
+echo "[collect] kernel trace"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-block-calib > "$D/trace.log" 2>&1
+echo "[collect] pmc fetch"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib > "$D/fetch.log" 2>&1
+echo "[collect] pmc write"
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib > "$D/write.log" 2>&1
+cd "$R"
+echo "[collect] families"; timeout -k 10 600 python3 -u tools/bench_families.py > "$D/families.json" 2> "$D/families.err"
+echo "[collect] blocks"
+timeout -k 10 300 python3 -u tools/bench_block.py --model 13b --amp 2>/dev/null | grep '^{' > "$D/blocks_extra.jsonl"
+timeout -k 10 300 python3 -u tools/bench_block.py --model 70b --abits 8 2>/dev/null | grep '^{' >> "$D/blocks_extra.jsonl"
+timeout -k 10 300 python3 -u tools/bench_block.py --model 70b --abits 8 --amp 2>/dev/null | grep '^{' >> "$D/blocks_extra.jsonl"
+echo "[collect] fused-operator A/B"; timeout -k 10 300 python3 -u tools/ab_block.py --model 7b --amp --reps 5 2>/dev/null | grep '^{' > "$D/ab_block.json"
+cd /tmp
+echo "[collect] block step trace"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/block7b" -- python3 "$R/tools/bench_block.py" --model 7b --amp > "$D/block7b.log" 2>&1
+echo "[collect] done"

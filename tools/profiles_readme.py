@@ -48,6 +48,8 @@ def main():
          "(gfx950 reports half of a 16 B/lane streaming read) and WRITE_SIZE·1024 |",
          f"| `{tag}_families.json` | `tools/bench_families.py`: every operator family on the baseline's named configurations |",
          f"| `{tag}_blocks_extra.jsonl` | `tools/bench_block.py` for the Llama-2-13B and Llama-2-70B shaped blocks |",
+         f"| `{tag}_block7b_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of `tools/bench_block.py --model 7b --amp` (the calibration step incl. GEMMs) |",
+         f"| `{tag}_ab_block.json` | `tools/ab_block.py --model 7b --amp`: the step with each fused operator chain switched off in turn (interleaved runs, medians) |",
          "| `traffic.json` | HBM bytes per bench step and kernel family (from the PMC passes above), read by `bench.py` for `roofline.traffic` |\n",
          f"## Final numbers of the round (`{tag}_bench.json.log`)\n",
          f"`value` = {b['value']} GB/s algorithmic over the whole step ({b['ms_per_step']} ms, {b['frac_hbm_peak'] * 100:.1f} % of the 8 TB/s peak), HIP-graph replay.\n",
@@ -92,14 +94,20 @@ def main():
         L.append(f"| {e['model']}, W{e['w_bits']}A{e['a_bits']} per-tensor static, {'LET+' if e['let'] else ''}LWC, {e['precision']} | {e['s_per_step']} | — | "
                  f"projected: {e['s_per_layer_projected_128x20']} s/layer on one GPU; peak memory {e['peak_mem_GiB']} GiB |")
     L.append("")
-    L.append("GPU time of a Llama-2-7B fp16 step by kernel (rocprofv3 kernel trace of `tools/bench_block.py --model 7b --amp`, final build): hipBLASLt "
-             "GEMMs 42 %, this library's kernels 30.5 % (LET-fused weight quantizer 11.7 %, activation quantizers 11.9 %, fused attention-score "
-             "pass 3.4 %, plain weight quantizer and gathers 3.5 %), reductions 5.8 %, dtype casts / copies 5.8 %, other PyTorch elementwise kernels "
-             "(rotary, SwiGLU, RMSNorm, autograd adds) 14.7 %, optimizer 1 %.  History of the fp16 step on the same shape: 13.2 ms with LET in PyTorch ops → 12.3 ms with the "
-             "LET-fused kernels → 11.4 ms with the two-kernel LET backward and fp16 weight output → 9.8 ms without the per-step host round trips "
-             "(loss / norm trace on the device, `truncate_number` as `torch.where`) → 7.8 ms with the fused attention-score pass.\n")
-    L.append("LET-fused kernels alone (`tools/bench_let.py`, [4096,4096] fp32): forward 34–36 µs (3.8 TB/s over read W + write Wq), backward rows "
-             "37 µs + columns 34 µs + two 5 µs folds (reads W and g twice, writes only vectors); the op chain it replaces costs > 200 µs.\n")
+    L.append("GPU time of a Llama-2-7B fp16 calibration run by kernel (`" + tag + "_block7b_kernel_stats.csv`): hipBLASLt GEMMs 50 %, this "
+             "library's kernels 31 % (LET-fused weight quantizer 12.8 %, activation quantizers 8.0 %, fused attention-score pass 4.8 %, "
+             "RMSNorm / rotary / bias-gradient column sums 4.4 %, plain weight quantizer 0.7 %), dtype casts / copies / cat 7 %, other "
+             "PyTorch elementwise kernels (SwiGLU, residual adds, loss, small LET vector ops) 9 %, reductions 0.9 %, optimizer 0.7 %.  "
+             "History of the fp16 step on the same shape: 13.2 ms with LET in PyTorch ops → 12.3 ms with the LET-fused kernels → 11.4 ms with "
+             "the two-kernel LET backward and fp16 weight output → 9.8 ms without the per-step host round trips (loss / norm trace on the "
+             "device, `truncate_number` as `torch.where`) → 7.8 ms with the fused attention-score pass → 7.1–7.3 ms with the fused RMSNorm, "
+             "the column-sum bias gradient, the rotary kernel, narrow per-tensor slabs folded to wide rows, the per-cluster parameter "
+             "kernels sliced over several blocks and the reciprocal-product LET backward (boxes differ by ±3 %; "
+             f"`{tag}_ab_block.json` holds same-box differences).  Llama-2-70B (no LET) under fp16 autocast: 17.9 → 15.3 ms per step and "
+             "11.6 → 9.4 GiB since plain fp32 weights are quantized straight into fp16.\n")
+    L.append("LET-fused kernels alone (`tools/bench_let.py`, [4096,4096] fp32): forward 34–36 µs (3.8 TB/s over read W + write Wq), backward 66 µs "
+             "(rows + columns kernel + two 5 µs folds; reads W and g twice, writes only vectors; 81 µs before the divisions became "
+             "corrected reciprocal products); the op chain it replaces costs > 200 µs.\n")
     L.append(f"## Operator families on the baseline's named configurations (`{tag}_families.json`, `tools/bench_families.py`)\n")
     L.append("One HIP graph per configuration over rotating buffer sets larger than the Infinity Cache, median of 7 replays (run-to-run spread "
              "≈ ±8 %).  Algorithmic bytes: forward 2ns, backward 3ns (2ns without dx), calibrate+quantize 3ns, gather 2ns.  "
