@@ -140,6 +140,7 @@ class UniformRowFQBatch(torch.autograd.Function):
         for o, s, z in zip(outs, scales, rzps):
             ret += [o, s, z]
         ctx.mark_non_differentiable(*scales, *rzps)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the scale / zero-point outputs
         return tuple(ret)
 
     @staticmethod
@@ -171,6 +172,7 @@ class UniformRowFQ(torch.autograd.Function):
         ctx.save_for_backward(x, up, low, row_bits)
         ctx.cfg = (n_bits, symmetric, group, clamp_asym)
         ctx.mark_non_differentiable(scale, rzp)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the scale / zero-point outputs
         return out, scale, rzp
 
     @staticmethod
@@ -179,7 +181,7 @@ class UniformRowFQ(torch.autograd.Function):
         n_bits, symmetric, group, clamp_asym = ctx.cfg
         need_dx = ctx.needs_input_grad[0]
         need_p = up is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        if not (need_dx or need_p):
+        if g is None or not (need_dx or need_p):
             return (None,) * 8
         dx, d_up, d_low = rowquant_uniform_bwd(g.contiguous(), x, n_bits, symmetric, up, low, group, row_bits,
                                                clamp_asym, want_dx=need_dx)
@@ -773,11 +775,13 @@ class LetRowFQ(torch.autograd.Function):
                                                    out_dtype=torch.float16 if half_out else None)
         ctx.save_for_backward(w, csf, rsf, shf, up, low)
         ctx.cfg = (bool(rs_div), int(n_bits), bool(symmetric))
+        ctx.half_out = bool(half_out)
         ctx.shapes = tuple(None if t is None else t.shape for t in (cs, rs, shift))
         ctx.mark_non_differentiable(scale, rzp)
         if wshift is None:
             wshift = w.new_zeros(())  # placeholder so that the output arity is fixed
             ctx.mark_non_differentiable(wshift)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the scale / zero-point / placeholder outputs
         return out, wshift, scale, rzp
 
     @staticmethod
@@ -785,6 +789,12 @@ class LetRowFQ(torch.autograd.Function):
         w, cs, rs, sh, up, low = ctx.saved_tensors
         rs_div, n_bits, symmetric = ctx.cfg
         need = ctx.needs_input_grad
+        if g is None and g_wshift is None:
+            return (None,) * 10
+        if g is None:  # only w @ shift was used
+            g = torch.zeros(w.shape, dtype=torch.float16 if ctx.half_out else w.dtype, device=w.device)
+        if g_wshift is None and sh is not None:
+            g_wshift = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         gw = g_wshift.contiguous() if (sh is not None and g_wshift is not None) else None
         d_cs, d_rs, d_shift, d_up, d_low = let_rowquant_bwd(g.contiguous(), gw, w, cs, rs, rs_div, sh, up, low, n_bits,
                                                             symmetric, want_cs=need[1], want_rs=need[2], want_shift=need[4])
@@ -897,6 +907,7 @@ class Exp2RowFQ(torch.autograd.Function):
         ctx.save_for_backward(x, up, low)
         ctx.cfg = (n_bits, group)
         ctx.mark_non_differentiable(scale)
+        ctx.set_materialize_grads(False)
         return out, scale
 
     @staticmethod
@@ -904,7 +915,7 @@ class Exp2RowFQ(torch.autograd.Function):
         x, up, low = ctx.saved_tensors
         n_bits, group = ctx.cfg
         need_dx = ctx.needs_input_grad[0]
-        if not (need_dx or (up is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))):
+        if g is None or not (need_dx or (up is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))):
             return (None,) * 5
         dx, d_up, d_low = rowquant_exp2_bwd(g.contiguous(), x, n_bits, up, low, group, want_dx=need_dx)
         return dx, d_up, d_low, None, None
@@ -920,6 +931,7 @@ class Exp1RowFQ(torch.autograd.Function):
         if mid is None:
             mid = scale.new_empty(0)
         ctx.mark_non_differentiable(scale, mid)
+        ctx.set_materialize_grads(False)
         return out, scale, mid
 
     @staticmethod
@@ -927,7 +939,7 @@ class Exp1RowFQ(torch.autograd.Function):
         x, up, low = ctx.saved_tensors
         n_bits, symmetric, group = ctx.cfg
         need_dx = ctx.needs_input_grad[0]
-        if not (need_dx or (up is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))):
+        if g is None or not (need_dx or (up is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))):
             return (None,) * 6
         dx, d_up, d_low = rowquant_exp1_bwd(g.contiguous(), x, n_bits, symmetric, up, low, group, want_dx=need_dx)
         return dx, d_up, d_low, None, None, None
