@@ -64,7 +64,27 @@ def ptr(t):
 
 
 def stream_of(t: torch.Tensor):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    # the raw handle of torch's current stream on t's device (no Stream object: this runs once per kernel launch)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(t.device.index))
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """Context manager that makes ``dev`` the current device for a launch; free when it already is (the usual
+    case: one process per GPU), since torch.cuda.device() costs several microseconds per call."""
+    if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def check_gpu(*tensors):

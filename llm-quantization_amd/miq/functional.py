@@ -49,7 +49,7 @@ def rowquant_uniform_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, gro
         raise L.MiqError(f"LWC factors must be {rows} values of dtype {x.dtype}")
     if row_bits is not None and (row_bits.numel() != rows or row_bits.dtype != torch.float32):
         raise L.MiqError(f"row_bits must be {rows} float32 values")
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_uniform_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(row_bits), L.ptr(out),
                L.ptr(scale), L.ptr(rzp), L.ptr(codes), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)),
                L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)), L.i32(L.dtype_code(x)),
@@ -66,7 +66,7 @@ def rowquant_uniform_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low
     dx = torch.empty_like(x) if want_dx else None
     d_up = torch.empty_like(up) if up is not None else None
     d_low = torch.empty_like(low) if low is not None else None
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_uniform_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(row_bits),
                L.ptr(dx), L.ptr(d_up), L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)),
                L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)), L.i32(L.dtype_code(x)),
@@ -95,7 +95,7 @@ def rowquant_uniform_fwd_batch(xs, n_bits: int, symmetric: bool, ups=None, lows=
     scales = [torch.empty((x.shape[0], 1), dtype=x.dtype, device=dev) for x in xs]
     rzps = [torch.empty_like(s) for s in scales]
     O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_uniform_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(outs), _ptr_table(scales), _ptr_table(rzps), O, L.i64(I),
                L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(xs[0])),
@@ -115,7 +115,7 @@ def rowquant_uniform_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, l
     d_lows = [torch.empty_like(u) for u in lows] if lwc else None
     O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
     none = [None] * len(xs)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_uniform_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(dxs) if want_dx else None, _ptr_table(d_ups if lwc else none),
                _ptr_table(d_lows if lwc else none), O, L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
@@ -248,7 +248,7 @@ def act_calibrate(x2d, n_bits: int, metric: str, layout: ClusterLayout, cached_m
         raise L.MiqError("reorder index must be int32 on the device")
     code = L.dtype_code(x2d)
     st = L.stream_of(x2d)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_colstat_minmax", L.ptr(x2d), L.i64(R), L.i64(C), L.ptr(part[0]), L.ptr(part[1]), L.i32(nchunk),
                L.i32(code), st)
         fold = nchunk
@@ -277,7 +277,7 @@ def channel_minmax(x2d):
     R, C = x2d.shape
     nchunk = colstat_chunks(R, C, x2d.dtype)
     part = torch.empty((2, nchunk, C), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_colstat_minmax", L.ptr(x2d), L.i64(R), L.i64(C), L.ptr(part[0]), L.ptr(part[1]), L.i32(nchunk),
                L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
     return part[0].amin(0), part[1].amax(0)
@@ -289,7 +289,7 @@ def row_absmean_accum(g2d, acc):
     O, I = g2d.shape
     if acc.dtype != torch.float32 or acc.numel() != O or not acc.is_contiguous():
         raise L.MiqError("accumulator must be a contiguous float32 vector with one entry per row")
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_row_absmean_accum", L.ptr(g2d), L.ptr(acc), L.i64(O), L.i64(I), L.i32(L.dtype_code(g2d)), L.stream_of(g2d))
     return acc
 
@@ -299,7 +299,7 @@ def colquant_fwd(x2d, scale, rzp, n_bits: int, want_codes: bool = False):
     R, C = x2d.shape
     out = torch.empty_like(x2d)
     codes = torch.empty((R, C), dtype=torch.uint8, device=dev) if want_codes else None
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_colquant_fwd", L.ptr(x2d), L.ptr(scale), L.ptr(rzp), L.ptr(out), L.ptr(codes), L.i64(R), L.i64(C),
                L.i32(int(n_bits)), L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
     return out, codes
@@ -317,7 +317,7 @@ def act_calib_quant_fwd(x2d, n_bits: int, metric: str, layout: ClusterLayout, ca
     outs = torch.empty((5, C), dtype=x2d.dtype, device=dev)
     out = torch.empty_like(x2d)
     codes = torch.empty((R, C), dtype=torch.uint8, device=dev) if want_codes else None
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_act_calib_quant_fwd", L.ptr(x2d), L.ptr(cached_min), L.ptr(cached_max),
                L.i32(1 if metric == "ema_minmax" else 0), L.ptr(layout.starts), L.i32(layout.n_clusters),
                L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(ws), L.ptr(out), L.ptr(codes), L.ptr(outs[0]), L.ptr(outs[1]),
@@ -343,7 +343,7 @@ def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
         args = (L.ptr(None),) * 5 + (L.i32(0), L.i64(0), L.ptr(None))
     tail = (L.i32(nchunk), L.ptr(dx), L.i64(R), L.i64(C), L.i32(int(n_bits)))
     code, st = L.i32(L.dtype_code(x2d)), L.stream_of(x2d)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         if route is not None and dp is not None and dp.active and dp.sync_stats:
             import torch.distributed as tdist
             L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(1), code, st)
@@ -362,7 +362,7 @@ def gather_lastdim(x, idx_i32):
         raise L.MiqError("gather index must be an int32 tensor with one entry per channel")
     R = x.numel() // C if C else 0
     out = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_gather_lastdim", L.ptr(x), L.ptr(idx_i32), L.ptr(out), L.i64(R), L.i64(C), L.i32(L.dtype_code(x)),
                L.stream_of(x))
     return out
@@ -404,7 +404,7 @@ def gather_layernorm_fwd(x, idx_i32, weight, bias, eps: float, out_dtype=None):
     rstd = torch.empty(stat_shape, dtype=torch.float32, device=dev)
     wb = weight if weight is not None else bias
     w_code = L._DT[wb.dtype] if wb is not None else L.F32
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_gather_layernorm_fwd", L.ptr(x), L.ptr(idx_i32), L.ptr(weight), L.ptr(bias), L.ptr(out), L.ptr(mean),
                L.ptr(rstd), L.i64(R), L.i64(C), L.f32(float(eps)), L.i32(L.dtype_code(x)), L.i32(w_code),
                L.i32(L.dtype_code(out)), L.stream_of(x))
@@ -469,7 +469,7 @@ class MaskedSoftmax(torch.autograd.Function):
         if mask is not None:
             m = mask.expand(B, 1, Q, K).contiguous() if mask.shape[0] != B and B > 1 else mask.contiguous()
         dev = L.check_gpu(x, m)
-        with torch.cuda.device(dev):
+        with L.on_device(dev):
             L.call("miq_masked_softmax_fwd", L.ptr(x), L.ptr(m), L.ptr(out), L.i64(B * H * Q), L.i64(K), L.i64(H * Q), L.i64(Q),
                    L.f32(float(div)), L.i32(L.dtype_code(x)), L.i32(L.dtype_code(m) if m is not None else L.F32), L.stream_of(x))
         ctx.save_for_backward(out)
@@ -482,7 +482,7 @@ class MaskedSoftmax(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty_like(p)
         K = p.shape[-1]
-        with torch.cuda.device(p.device):
+        with L.on_device(p.device):
             L.call("miq_masked_softmax_bwd", L.ptr(p), L.ptr(g), L.ptr(dx), L.i64(p.numel() // K), L.i64(K), L.f32(ctx.div),
                    L.i32(L.dtype_code(p)), L.stream_of(p))
         return dx, None, None
@@ -510,7 +510,7 @@ class RMSNorm(torch.autograd.Function):
         R = x.numel() // C
         out = torch.empty_like(x)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with L.on_device(dev):
             L.call("miq_rmsnorm_fwd", L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), L.ptr(rstd), L.i64(R), L.i64(C),
                    L.f32(float(eps)), L.i32(L.dtype_code(x)), L.stream_of(x))
         ctx.save_for_backward(x, w, rstd)
@@ -533,7 +533,7 @@ class RMSNorm(torch.autograd.Function):
         ws = None
         if need_w or need_b:
             ws = torch.empty(int(L.lib().miq_rmsnorm_workspace(L.i64(R), L.i64(C))), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with L.on_device(x.device):
             L.call("miq_rmsnorm_bwd", L.ptr(gy), L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws),
                    L.i64(R), L.i64(C), L.i32(L.dtype_code(x)), L.stream_of(x))
         return dx, dw, db, None
@@ -555,7 +555,7 @@ def rotary_supported(x, cos, sin) -> bool:
 def _rotary_call(x, cos, sin, out, backward: bool):
     B, H, T, D = x.shape
     tab_bs = T * D if cos.shape[0] > 1 else 0
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         L.call("miq_rotary", L.ptr(x), L.ptr(cos), L.ptr(sin), L.ptr(out), L.i64(B), L.i64(H), L.i64(T), L.i64(D),
                L.i64(x.stride(0)), L.i64(x.stride(1)), L.i64(x.stride(2)), L.i64(out.stride(0)), L.i64(out.stride(1)),
                L.i64(out.stride(2)), L.i64(tab_bs), L.i32(int(backward)), L.i32(L.dtype_code(x)), L.stream_of(x))
@@ -592,7 +592,7 @@ def col_sum(x2d):
     out = torch.empty(C, dtype=torch.float32, device=dev)
     n = int(L.lib().miq_col_sum_workspace(L.i64(R), L.i64(C)))
     ws = torch.empty(n, dtype=torch.float32, device=dev) if n > C else None
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_col_sum", L.ptr(x2d), L.ptr(out), L.ptr(ws), L.i64(R), L.i64(C), L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
     return out
 
@@ -732,7 +732,7 @@ def let_rowquant_fwd(w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, preac
     scale = torch.empty((O, 1), dtype=w.dtype, device=dev)
     rzp = torch.empty_like(scale)
     wshift = torch.empty(O, dtype=w.dtype, device=dev) if shift is not None else None
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_let_rowquant_fwd", L.ptr(w), L.ptr(cs), L.ptr(rs), L.i32(int(bool(rs_div))), L.ptr(shift), L.ptr(up),
                L.ptr(low), L.ptr(out), L.ptr(scale), L.ptr(rzp), L.ptr(wshift), L.i64(O), L.i64(I), L.i32(int(n_bits)),
                L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(out)), L.stream_of(w))
@@ -754,7 +754,7 @@ def let_rowquant_bwd(g, g_wshift, w, cs, rs, rs_div, shift, up, low, n_bits, sym
     ws = None
     if want_cs or want_shift:
         ws = torch.empty(int(L.lib().miq_let_workspace(L.i64(O), L.i64(I))), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_let_rowquant_bwd", L.ptr(g), L.ptr(g_wshift), L.ptr(w), L.ptr(cs), L.ptr(rs), L.i32(int(bool(rs_div))),
                L.ptr(shift), L.ptr(up), L.ptr(low), L.ptr(d_cs), L.ptr(d_rs), L.ptr(d_shift), L.ptr(d_up), L.ptr(d_low),
                L.ptr(ws), L.i64(O), L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
@@ -818,7 +818,7 @@ def rowquant_exp2_fwd(x, n_bits: int, up=None, low=None, group: int = 0, preacti
     _check_lwc(x, up, low, rows)
     out = torch.empty_like(x)
     scale = torch.empty((rows, 1), dtype=x.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_exp2_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(out), L.ptr(scale), L.i64(O), L.i64(I),
                L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(x)), L.stream_of(x))
     return out, scale
@@ -830,7 +830,7 @@ def rowquant_exp2_bwd(grad_out, x, n_bits: int, up=None, low=None, group: int = 
     dx = torch.empty_like(x) if want_dx else None
     d_up = torch.empty_like(up) if up is not None else None
     d_low = torch.empty_like(low) if low is not None else None
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_exp2_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(dx), L.ptr(d_up),
                L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)),
                L.i32(L.dtype_code(x)), L.stream_of(x))
@@ -845,7 +845,7 @@ def rowquant_exp1_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, group:
     out = torch.empty_like(x)
     scale = torch.empty((rows, 1), dtype=x.dtype, device=dev)
     mid = None if symmetric else torch.empty((rows, 1), dtype=x.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_exp1_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(out), L.ptr(scale), L.ptr(mid), L.i64(O),
                L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)),
                L.i32(L.dtype_code(x)), L.stream_of(x))
@@ -859,7 +859,7 @@ def rowquant_exp1_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low=No
     dx = torch.empty_like(x) if want_dx else None
     d_up = torch.empty_like(up) if up is not None else None
     d_low = torch.empty_like(low) if low is not None else None
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_exp1_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(dx), L.ptr(d_up),
                L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
                L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(x)), L.stream_of(x))
@@ -876,7 +876,7 @@ def rowquant_mix_fwd(x, n_bits_rows, symmetric: bool, up=None, low=None, group: 
     if n_bits_rows.numel() != rows:
         raise L.MiqError(f"n_bits must have {rows} entries")
     out = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_mix_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(n_bits_rows), L.ptr(out), L.i64(O), L.i64(I),
                L.i64(g), L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)),
                L.i32(_flags(False, preactivated)), L.i32(L.F32), L.stream_of(x))
@@ -891,7 +891,7 @@ def rowquant_mix_bwd(grad_out, x, n_bits_rows, symmetric: bool, up=None, low=Non
     d_up = torch.empty_like(up) if up is not None else None
     d_low = torch.empty_like(low) if low is not None else None
     d_n = torch.empty_like(n_bits_rows)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_rowquant_mix_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(n_bits_rows), L.ptr(dx),
                L.ptr(d_up), L.ptr(d_low), L.ptr(d_n), L.i64(O), L.i64(I), L.i64(g), L.i32(int(bool(symmetric))),
                L.i32(int(bool(hard))), L.f32(float(threshold)), L.i32(_flags(False, preactivated)), L.i32(L.F32),
@@ -971,6 +971,6 @@ def reorder_index(xmax, xmin, n_heads: int = 1):
     xmin = xmin.float().contiguous()
     C = xmax.numel()
     out = torch.empty(C, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with L.on_device(dev):
         L.call("miq_reorder_index", L.ptr(xmax), L.ptr(xmin), L.i64(C), L.i32(int(n_heads)), L.ptr(out), L.stream_of(xmax))
     return out
