@@ -62,11 +62,20 @@ class _BlockBase(nn.Module):
 
     let = False
 
+    def _quant_modules(self):
+        """(name, module) of every QuantLinear / QuantMatMul, walked once: the calibration loop asks several times
+        per step and the module tree does not change after construction."""
+        cache = self.__dict__.get("_quant_module_cache")
+        if cache is None:
+            cache = [(n, m) for n, m in self.named_modules() if isinstance(m, (QuantLinear, QuantMatMul))]
+            self.__dict__["_quant_module_cache"] = cache
+        return cache
+
     def quant_linears(self):
-        return [(n, m) for n, m in self.named_modules() if isinstance(m, QuantLinear)]
+        return [(n, m) for n, m in self._quant_modules() if isinstance(m, QuantLinear)]
 
     def act_quantizers(self):
-        for _n, m in self.named_modules():
+        for _n, m in self._quant_modules():
             if isinstance(m, QuantLinear) and not m.disable_input_quant:
                 yield m.act_quantizer
             if isinstance(m, QuantMatMul):
@@ -76,9 +85,8 @@ class _BlockBase(nn.Module):
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.use_weight_quant = weight_quant
         self.use_act_quant = act_quant
-        for _n, m in self.named_modules():
-            if isinstance(m, (QuantLinear, QuantMatMul)):
-                m.set_quant_state(weight_quant, act_quant)
+        for _n, m in self._quant_modules():
+            m.set_quant_state(weight_quant, act_quant)
 
     def clear_temp_variable(self):
         for _n, m in self.quant_linears():

@@ -227,21 +227,13 @@ def init_let(qlayer, act_scales: Dict[str, torch.Tensor], act_shifts: Dict[str, 
 # the per-layer calibration
 # ------------------------------------------------------------------------------------------------
 def _free_act_stats(qlayer):
-    for _n, m in qlayer.named_modules():
-        if isinstance(m, QuantLinear) and not m.disable_input_quant:
-            m.act_quantizer.free()
-        if isinstance(m, QuantMatMul):
-            m.x1_quantizer.free()
-            m.x2_quantizer.free()
+    for q in qlayer.act_quantizers():
+        q.free()
 
 
 def _set_eval(qlayer):
-    for _n, m in qlayer.named_modules():
-        if isinstance(m, QuantLinear) and not m.disable_input_quant:
-            m.act_quantizer.set_eval_mode()
-        if isinstance(m, QuantMatMul):
-            m.x1_quantizer.set_eval_mode()
-            m.x2_quantizer.set_eval_mode()
+    for q in qlayer.act_quantizers():
+        q.set_eval_mode()
 
 
 def _set_dp(qlayer, dp):

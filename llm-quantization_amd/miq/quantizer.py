@@ -185,14 +185,13 @@ class UniformAffineQuantizer(nn.Module):
     def _publish(self, x, st, kind):
         shape = self._stat_shape(x, kind)
         pick = (lambda v: v[0].reshape(shape)) if kind == "tensor" else (lambda v: v.reshape(shape))
-        for name in ("scale", "zero_point", "round_zero_point"):
+        for name, key in (("scale", "scale"), ("zero_point", "zp"), ("round_zero_point", "rzp")):
             if name in self._buffers:
-                del self._buffers[name]
-            elif hasattr(self, name):
+                self._buffers[name] = pick(st[key])  # already a buffer: rebinding it is a dict store
+                continue
+            if hasattr(self, name):
                 delattr(self, name)
-        self.register_buffer("scale", pick(st["scale"]))
-        self.register_buffer("zero_point", pick(st["zp"]))
-        self.register_buffer("round_zero_point", pick(st["rzp"]))
+            self.register_buffer(name, pick(st[key]))
         self.cached_xmin = pick(st["cmin"])
         self.cached_xmax = pick(st["cmax"])
         self._vec = (st["scale"], st["rzp"], st["cmin"], st["cmax"])
