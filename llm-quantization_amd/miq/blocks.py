@@ -213,11 +213,17 @@ class _BlockBase(nn.Module):
         m.use_temporary_parameter = True
 
     def _truncate_scales(self):
+        # the smoothing scales are parameters of the block itself (init_let registers them): the list is rebuilt only
+        # when that dict changes, not by a walk over the module tree on every step
+        key = tuple(self._parameters)
+        cache = self.__dict__.get("_smooth_scale_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, [p for n, p in self.named_parameters() if "smooth_scale" in n])
+            self.__dict__["_smooth_scale_cache"] = cache
         with torch.no_grad():
-            for n, p in self.named_parameters():
-                if "smooth_scale" in n:
-                    # in place (the reference rebinds .data): the parameter keeps its storage
-                    p.copy_(truncate_number(p))
+            for p in cache[1]:
+                # in place (the reference rebinds .data): the parameter keeps its storage
+                p.copy_(truncate_number(p))
 
 
 class _OPTAttention(nn.Module):

@@ -362,6 +362,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
             sl = slice(i0, i0 + cfg.batch_size)
             return quant_inps[sl], fp_inps[sl], (fp_inps_2[sl] if cfg.aug_loss else None)
 
+        omni_params = list(qlayer.omni_parameters(cfg.use_shift))  # one walk of the module tree, not one per step
         for epoch in range(cfg.epochs):
             if cfg.weight_mix_quant:
                 if epoch == round(cfg.epochs * 0.5):
@@ -372,7 +373,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
             for j in range(steps_per_epoch):
                 optimizer.zero_grad()
                 loss = forward_backward(*batch(j))
-                norm, buf = scaler.step(optimizer, qlayer.omni_parameters(cfg.use_shift), dp, buf)
+                norm, buf = scaler.step(optimizer, omni_params, dp, buf)
                 trace[0, j] = loss
                 trace[1, j] = norm
                 _free_act_stats(qlayer)

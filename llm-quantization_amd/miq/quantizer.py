@@ -192,9 +192,12 @@ class UniformAffineQuantizer(nn.Module):
             if hasattr(self, name):
                 delattr(self, name)
             self.register_buffer(name, pick(st[key]))
-        self.cached_xmin = pick(st["cmin"])
-        self.cached_xmax = pick(st["cmax"])
-        self._vec = (st["scale"], st["rzp"], st["cmin"], st["cmax"])
+        # plain attributes (never parameters or buffers): skip nn.Module.__setattr__'s registration checks, this runs
+        # once per activation quantizer call
+        d = self.__dict__
+        d["cached_xmin"] = pick(st["cmin"])
+        d["cached_xmax"] = pick(st["cmax"])
+        d["_vec"] = (st["scale"], st["rzp"], st["cmin"], st["cmax"])
 
     def _cached_vectors(self, x):
         """[C] vectors of the cached statistics (or None, None)."""
