@@ -321,6 +321,14 @@ int miq_rotary(const void* x, const void* cos, const void* sin, void* out, int64
                int64_t xs_b, int64_t xs_h, int64_t xs_t, int64_t os_b, int64_t os_h, int64_t os_t,
                int64_t table_batch_stride, int backward, int dtype, void* stream);
 
+/*
+ * truncate_number (models/transformation.py:4-20) applied in place to up to 16 vectors in one launch:
+ * x[|x| < threshold] = sign(x) * threshold (zeros stay zero, NaN stays NaN).  The decoder layers call it on every
+ * smoothing scale before each training step (models/int_llama_layer.py:279-285, models/int_opt_layer.py:390-396).
+ * ptrs / sizes are HOST arrays of n device pointers / element counts, all of `dtype`.
+ */
+int miq_truncate_inplace(void* const* ptrs, const int64_t* sizes, int n, float threshold, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

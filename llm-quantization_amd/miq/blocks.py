@@ -23,6 +23,8 @@ from .let import (smooth_fc_fc_inplace, smooth_fc_fc_temporary, smooth_ln_fcs_in
                   smooth_q_k_inplace, smooth_q_k_temporary, truncate_number)
 from .omni_norm import OmniLayerNorm, OmniLlamaRMSNorm
 
+TRUNCATE_THRESHOLD = 1e-2  # truncate_number's default where the decoder layers call it (models/transformation.py:18)
+
 
 def quant_args(wbits=4, abits=4, w_symmetric=False, group_size=None, lwc=True, a_dynamic_method="per_cluster",
                a_dynamic=False, metric="ema_minmax", weight_exp_quant=False, weight_mix_quant=False,
@@ -220,10 +222,15 @@ class _BlockBase(nn.Module):
         if cache is None or cache[0] != key:
             cache = (key, [p for n, p in self.named_parameters() if "smooth_scale" in n])
             self.__dict__["_smooth_scale_cache"] = cache
+        ps = cache[1]
         with torch.no_grad():
-            for p in cache[1]:
-                # in place (the reference rebinds .data): the parameter keeps its storage
-                p.copy_(truncate_number(p))
+            # in place (the reference rebinds .data): the parameters keep their storage
+            if ps and all(p.is_cuda and p.is_contiguous() and p.dtype == ps[0].dtype for p in ps) \
+                    and ps[0].dtype in (torch.float32, torch.float16):
+                F.truncate_inplace_([p.data for p in ps], TRUNCATE_THRESHOLD)  # one launch for all scales
+            else:
+                for p in ps:
+                    p.copy_(truncate_number(p))
 
 
 class _OPTAttention(nn.Module):

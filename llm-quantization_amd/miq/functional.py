@@ -539,6 +539,25 @@ class RMSNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def truncate_inplace_(tensors, threshold: float = 1e-2):
+    """x[|x| < threshold] = sign(x) * threshold, in place, for a list of contiguous GPU tensors of one dtype
+    (miq_truncate_inplace: one launch per 16 tensors)."""
+    import ctypes
+    tensors = [t for t in tensors if t.numel()]
+    if not tensors:
+        return
+    dev = L.check_gpu(*tensors)
+    code = L.dtype_code(tensors[0])
+    if any(t.dtype != tensors[0].dtype for t in tensors):
+        raise L.MiqError("truncate_inplace_: tensors of one dtype per call")
+    with L.on_device(dev):
+        for i in range(0, len(tensors), 16):
+            part = tensors[i:i + 16]
+            sizes = (ctypes.c_int64 * len(part))(*[t.numel() for t in part])
+            L.call("miq_truncate_inplace", _ptr_table(part), sizes, L.i32(len(part)), L.f32(float(threshold)), L.i32(code),
+                   L.stream_of(part[0]))
+
+
 def rotary_supported(x, cos, sin) -> bool:
     if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.float32) and x.numel() > 0):
         return False

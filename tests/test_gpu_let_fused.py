@@ -127,3 +127,25 @@ def test_half_output_and_half_gradient_are_casts():
     b = F.let_rowquant_bwd(g16.float(), dev(d["gb"]), *args[:3], True, *args[4:])
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_truncate_inplace_matches_truncate_number(dt):
+    """miq_truncate_inplace against the mirror of the reference's TruncateFunction (models/transformation.py:4-20),
+    bit for bit: zeros stay zero, NaN stays NaN, more vectors than one launch takes."""
+    from miq.let import truncate_number
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    vecs = []
+    for i in range(19):
+        v = (torch.randn(37 + 300 * i, generator=g, device="cuda:0") * 0.02).to(dt)
+        v[::7] = 0
+        v[3] = float("nan")
+        v[5] = 0.01
+        v[6] = -0.0099
+        vecs.append(v)
+    vecs.append(torch.empty(0, device="cuda:0", dtype=dt))
+    want = [truncate_number(v.clone()) for v in vecs]
+    F.truncate_inplace_(vecs, 1e-2)
+    for a, b in zip(vecs, want):
+        assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+        assert torch.equal(torch.signbit(a), torch.signbit(b))
