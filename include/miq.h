@@ -301,10 +301,12 @@ int miq_rmsnorm_bwd(const void* grad_out, const void* x, const float* weight, co
  * Column sums out[c] = sum_r x[r, c] (fp32 [C]) of a row-major [R, C] fp32 / fp16 matrix: the bias gradient of the
  * F.linear inside QuantLinear.forward (quantize/int_linear.py:86), which autograd computes with a reduction over
  * the slow dimension.  workspace: miq_col_sum_workspace(R, C) floats (may be NULL when that is <= C, i.e. one row
- * chunk).  Deterministic summation order.
+ * chunk).  Deterministic summation order.  round_dtype = MIQ_F16 rounds every sum to fp16 before it is stored as fp32
+ * (what an fp16 reduction returns, overflow to inf included: the loss scaler relies on it); MIQ_F32 stores the sum.
  */
 int64_t miq_col_sum_workspace(int64_t R, int64_t C);
-int miq_col_sum(const void* x, float* out, float* workspace, int64_t R, int64_t C, int dtype, void* stream);
+int miq_col_sum(const void* x, float* out, float* workspace, int64_t R, int64_t C, int dtype, int round_dtype,
+                void* stream);
 
 /*
  * Rotary position embedding of the Llama query / key states in front of the q.k^T quantizers

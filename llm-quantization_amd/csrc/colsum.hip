@@ -11,7 +11,7 @@ namespace miq {
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-k_colsum_partial(const T* __restrict__ x, long long R, int C, int rows_per_chunk, float* __restrict__ part) {
+k_colsum_partial(const T* __restrict__ x, long long R, int C, int rows_per_chunk, float* __restrict__ part, int round_half) {
     __shared__ float sm[4][64][VEC + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
@@ -47,12 +47,15 @@ k_colsum_partial(const T* __restrict__ x, long long R, int C, int rows_per_chunk
     if (wv != 0 || !valid) return;
     float* o = part + (long long)blockIdx.y * C + col0;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = (sm[0][lane][e] + sm[1][lane][e]) + (sm[2][lane][e] + sm[3][lane][e]);
+    for (int e = 0; e < VEC; ++e) {
+        const float v = (sm[0][lane][e] + sm[1][lane][e]) + (sm[2][lane][e] + sm[3][lane][e]);
+        o[e] = round_half ? rnd<__half>(v) : v;  // only set when this launch writes the final sums (one chunk)
+    }
 }
 
 // out[c] = sum over the nrows partial rows in a fixed order; block = 64 columns x 4 waves
 __global__ void __launch_bounds__(256)
-k_colsum_fold(const float* __restrict__ part, int nrows, int C, float* __restrict__ out) {
+k_colsum_fold(const float* __restrict__ part, int nrows, int C, float* __restrict__ out, int round_half) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -70,7 +73,10 @@ k_colsum_fold(const float* __restrict__ part, int nrows, int C, float* __restric
     }
     sm[w][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
-    if (w == 0 && c < C) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    if (w == 0 && c < C) {
+        const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        out[c] = round_half ? rnd<__half>(v) : v;
+    }
 }
 
 static inline int colsum_vec(const void* x, long long C, int dtype) {
@@ -88,14 +94,15 @@ static inline int colsum_chunks(long long R, long long C, int vec) {
 }
 
 template <typename T, int VEC>
-static void colsum_launch(const void* x, long long R, int C, float* out, float* ws, hipStream_t stream) {
+static void colsum_launch(const void* x, long long R, int C, float* out, float* ws, int round_half, hipStream_t stream) {
     const int nchunk = colsum_chunks(R, C, VEC);
     const int rpc = (int)((R + nchunk - 1) / nchunk);
     const unsigned tiles = (unsigned)(((C + VEC - 1) / VEC + 63) / 64);
     float* part = nchunk == 1 ? out : ws;
-    hipLaunchKernelGGL((k_colsum_partial<T, VEC>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, R, C, rpc, part);
+    hipLaunchKernelGGL((k_colsum_partial<T, VEC>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x, R, C, rpc, part,
+                       nchunk == 1 ? round_half : 0);
     if (nchunk > 1)
-        hipLaunchKernelGGL(k_colsum_fold, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, ws, nchunk, C, out);
+        hipLaunchKernelGGL(k_colsum_fold, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, ws, nchunk, C, out, round_half);
 }
 
 }  // namespace miq
@@ -113,10 +120,13 @@ extern "C" int64_t miq_col_sum_workspace(int64_t R, int64_t C) {
     return (int64_t)n * C;
 }
 
-extern "C" int miq_col_sum(const void* x, float* out, float* workspace, int64_t R, int64_t C, int dtype, void* stream) {
+extern "C" int miq_col_sum(const void* x, float* out, float* workspace, int64_t R, int64_t C, int dtype, int round_dtype,
+                           void* stream) {
     if (C == 0) return 0;
     MIQ_CHECK_ARG(out && C > 0 && C < (1ll << 31) && R >= 0 && R < (1ll << 40), "miq_col_sum: null pointer or bad shape");
     MIQ_CHECK_ARG(dtype == MIQ_F32 || dtype == MIQ_F16, "miq_col_sum: unsupported dtype %d", dtype);
+    MIQ_CHECK_ARG(round_dtype == MIQ_F32 || round_dtype == MIQ_F16, "miq_col_sum: unsupported rounding dtype %d", round_dtype);
+    const int rh = round_dtype == MIQ_F16;
     hipStream_t s = (hipStream_t)stream;
     if (R == 0) {
         if (hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) {
@@ -129,11 +139,11 @@ extern "C" int miq_col_sum(const void* x, float* out, float* workspace, int64_t 
     const int vec = colsum_vec(x, C, dtype);
     MIQ_CHECK_ARG(colsum_chunks(R, C, vec) == 1 || workspace, "miq_col_sum: workspace of miq_col_sum_workspace(R, C) floats required");
     if (dtype == MIQ_F32) {
-        if (vec == 4) colsum_launch<float, 4>(x, R, (int)C, out, workspace, s);
-        else colsum_launch<float, 1>(x, R, (int)C, out, workspace, s);
+        if (vec == 4) colsum_launch<float, 4>(x, R, (int)C, out, workspace, rh, s);
+        else colsum_launch<float, 1>(x, R, (int)C, out, workspace, rh, s);
     } else {
-        if (vec == 8) colsum_launch<__half, 8>(x, R, (int)C, out, workspace, s);
-        else colsum_launch<__half, 1>(x, R, (int)C, out, workspace, s);
+        if (vec == 8) colsum_launch<__half, 8>(x, R, (int)C, out, workspace, rh, s);
+        else colsum_launch<__half, 1>(x, R, (int)C, out, workspace, rh, s);
     }
     MIQ_CHECK_LAUNCH("miq_col_sum");
     return 0;

@@ -604,15 +604,17 @@ class RotaryEmb(torch.autograd.Function):
         return dx, None, None
 
 
-def col_sum(x2d):
-    """fp32 [C] column sums of a contiguous [R, C] fp32 / fp16 matrix (miq_col_sum)."""
+def col_sum(x2d, round_to=None):
+    """fp32 [C] column sums of a contiguous [R, C] fp32 / fp16 matrix (miq_col_sum); ``round_to=torch.float16``
+    rounds every sum to fp16 first (the value an fp16 reduction returns, inf on overflow)."""
     dev = L.check_gpu(x2d)
     R, C = x2d.shape
     out = torch.empty(C, dtype=torch.float32, device=dev)
     n = int(L.lib().miq_col_sum_workspace(L.i64(R), L.i64(C)))
     ws = torch.empty(n, dtype=torch.float32, device=dev) if n > C else None
     with L.on_device(dev):
-        L.call("miq_col_sum", L.ptr(x2d), L.ptr(out), L.ptr(ws), L.i64(R), L.i64(C), L.i32(L.dtype_code(x2d)), L.stream_of(x2d))
+        L.call("miq_col_sum", L.ptr(x2d), L.ptr(out), L.ptr(ws), L.i64(R), L.i64(C), L.i32(L.dtype_code(x2d)),
+               L.i32(L.F16 if round_to == torch.float16 else L.F32), L.stream_of(x2d))
     return out
 
 
@@ -655,7 +657,7 @@ class LinearBias(torch.autograd.Function):
             if need_b:
                 # rounded to the compute dtype first, like the reduction it replaces: an fp16 sum that overflows must
                 # become inf so that the loss scaler skips the step exactly when it would with F.linear
-                db = col_sum(g2).to(g2.dtype).to(ctx.in_dtypes[2])
+                db = col_sum(g2, round_to=g2.dtype).to(ctx.in_dtypes[2])
         return dx, dw, db
 
 

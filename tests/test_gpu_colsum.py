@@ -26,6 +26,13 @@ def test_col_sum_matches_fp64(R, C, dt):
     tol = 1e-6 * x.double().abs().sum(0) + 1e-6
     assert torch.all((got.double() - want).abs() <= tol)
     assert torch.equal(got, F.col_sum(x))  # fixed summation order
+    assert torch.equal(F.col_sum(x, round_to=torch.float16), got.half().float())
+
+
+def test_col_sum_rounded_to_half_overflows_to_inf():
+    x = torch.full((64, 16), 4096.0, device=DEV, dtype=torch.float16)
+    assert torch.all(F.col_sum(x) == 64 * 4096.0)
+    assert torch.all(torch.isinf(F.col_sum(x, round_to=torch.float16)))
 
 
 def test_col_sum_of_a_misaligned_view():
