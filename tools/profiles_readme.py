@@ -94,15 +94,17 @@ def main():
         L.append(f"| {e['model']}, W{e['w_bits']}A{e['a_bits']} per-tensor static, {'LET+' if e['let'] else ''}LWC, {e['precision']} | {e['s_per_step']} | — | "
                  f"projected: {e['s_per_layer_projected_128x20']} s/layer on one GPU; peak memory {e['peak_mem_GiB']} GiB |")
     L.append("")
-    L.append("GPU time of a Llama-2-7B fp16 calibration run by kernel (`" + tag + "_block7b_kernel_stats.csv`): hipBLASLt GEMMs 50 %, this "
-             "library's kernels 31 % (LET-fused weight quantizer 12.8 %, activation quantizers 8.0 %, fused attention-score pass 4.8 %, "
-             "RMSNorm / rotary / bias-gradient column sums 4.4 %, plain weight quantizer 0.7 %), dtype casts / copies / cat 7 %, other "
-             "PyTorch elementwise kernels (SwiGLU, residual adds, loss, small LET vector ops) 9 %, reductions 0.9 %, optimizer 0.7 %.  "
+    L.append("GPU time of a Llama-2-7B fp16 calibration run by kernel (`" + tag + "_block7b_kernel_stats.csv`): hipBLASLt GEMMs 51 %, this "
+             "library's kernels 31 % (LET-fused weight quantizer 13.1 %, activation quantizers 8.1 %, fused attention-score pass 4.8 %, "
+             "RMSNorm / rotary / bias-gradient column sums / truncate 4.5 %, plain weight quantizer 0.7 %), dtype casts / copies / cat "
+             "6.5 %, other PyTorch elementwise kernels (SwiGLU, residual adds, loss, small LET vector ops) 8 %, reductions 1 %, "
+             "optimizer 0.7 %; 4200 launches in the run against 4720 before the launch-count work.  "
              "History of the fp16 step on the same shape: 13.2 ms with LET in PyTorch ops → 12.3 ms with the LET-fused kernels → 11.4 ms with "
              "the two-kernel LET backward and fp16 weight output → 9.8 ms without the per-step host round trips (loss / norm trace on the "
-             "device, `truncate_number` as `torch.where`) → 7.8 ms with the fused attention-score pass → 7.1–7.3 ms with the fused RMSNorm, "
+             "device, `truncate_number` as `torch.where`) → 7.8 ms with the fused attention-score pass → 6.6–6.9 ms with the fused RMSNorm, "
              "the column-sum bias gradient, the rotary kernel, narrow per-tensor slabs folded to wide rows, the per-cluster parameter "
-             "kernels sliced over several blocks and the reciprocal-product LET backward (boxes differ by ±3 %; "
+             "kernels sliced over several blocks, the reciprocal-product LET backward, no materialised zero gradients, the "
+             "batched truncate kernel and in-kernel rounding of the bias gradient (boxes differ by ±3 %; "
              f"`{tag}_ab_block.json` holds same-box differences).  Llama-2-70B (no LET) under fp16 autocast: 17.9 → 15.3 ms per step and "
              "11.6 → 9.4 GiB since plain fp32 weights are quantized straight into fp16.\n")
     L.append("LET-fused kernels alone (`tools/bench_let.py`, [4096,4096] fp32): forward 34–36 µs (3.8 TB/s over read W + write Wq), backward 66 µs "
