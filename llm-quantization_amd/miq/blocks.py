@@ -181,14 +181,13 @@ class _BlockBase(nn.Module):
 
     half_weights = True  # under fp16 autocast, quantize plain fp32 weights straight into the fp16 tensor the linear uses
 
-    @classmethod
-    def _half_weight_path(cls, q, w) -> bool:
+    def _half_weight_path(self, q, w) -> bool:
         """Under fp16 autocast the linear casts its fp32 quantized weight to fp16 (and autograd casts the fp16 weight
         gradient back): 6 extra bytes per element each way.  The LET-fused kernel without factors is the plain
         row-wise quantizer with an fp16 store and an fp16 gradient load, so weights that are not themselves functions
         of trained tensors go through it."""
         from .quantizer import UniformAffineQuantizer
-        return (cls.half_weights and cls.fused_let and torch.is_autocast_enabled()
+        return (self.half_weights and self.fused_let and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") == torch.float16 and type(q) is UniformAffineQuantizer
                 and not w.requires_grad and w.dtype == torch.float32 and q.let_fusable(w))
 
@@ -199,11 +198,10 @@ class _BlockBase(nn.Module):
         return self.fused_let and all(type(m.weight_quantizer) is UniformAffineQuantizer and m.weight_quantizer.let_fusable(m.weight)
                                       for _n, m in self.quant_linears())
 
-    @staticmethod
-    def _let_linear(m, cs=None, rs=None, rs_div=True, shift=None):
+    def _let_linear(self, m, cs=None, rs=None, rs_div=True, shift=None):
         """temp_weight / temp_bias of one linear: quantize((W * cs) / rs or * rs); bias + W @ shift.
         The caller applies the row factor and the output shift to the bias (small vectors)."""
-        if cs is None and rs is None and shift is None and not _BlockBase._half_weight_path(m.weight_quantizer, m.weight):
+        if cs is None and rs is None and shift is None and not self._half_weight_path(m.weight_quantizer, m.weight):
             wq, wshift = m.weight_quantizer(m.weight), None  # nothing to fuse: the plain row kernels are leaner
         else:
             wq, wshift = m.weight_quantizer.forward_let(m.weight, cs, rs, rs_div, shift)
