@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: the fake-quantization hot path of one OmniQuant calibration step on a
-Llama-2-7B-shaped block (BASELINE.json configs[1]: W4A4, static per-cluster activation quantization
-with RPTQ channel reorder), synthetic data, one MI355X per rank.
+Llama-2-7B-shaped block (the configuration the headline metric is quoted on: W4A4, static per-cluster activation
+quantization with RPTQ channel reorder), synthetic data, one MI355X per rank.
 
 One "step" = everything the quantizer kernels do for ONE calibration sample of 2048 tokens
 (GEMMs / attention / layer norms are not part of this path and are not executed):

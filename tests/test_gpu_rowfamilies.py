@@ -227,7 +227,7 @@ def test_reorder_index_ties_are_stable_and_large():
 # ------------------------------------------------------------------------------------ benchmark shapes vs the oracle
 @pytest.mark.parametrize("shape,bits", [((4096, 4096), 3), ((11008, 4096), 3), ((4096, 11008), 4), ((1024, 28672), 2)])
 def test_exp2_llama_shapes_vs_oracle(shape, bits):
-    """Llama-2-7B weight shapes (BASELINE configs[2]: W3A16 exponential quantizer, fwd + STE bwd)."""
+    """Llama-2-7B weight shapes (the W3A16 exponential-quantizer configuration, fwd + STE bwd)."""
     x = synth.weight(shape[0], shape[1], 2)
     up, low = synth.lwc_factors(shape[0], 3)
     w = synth.grad_like(x, 4)
@@ -247,7 +247,7 @@ def test_exp2_llama_shapes_vs_oracle(shape, bits):
 
 @pytest.mark.parametrize("shape,hard", [((5120, 5120), False), ((13824, 5120), True), ((1280, 13824), False)])
 def test_mix_llama13b_shapes_vs_oracle(shape, hard):
-    """Llama-2-13B weight shapes (BASELINE configs[3]: learnable per-output-channel bits), soft and hard phase."""
+    """Llama-2-13B weight shapes (the learnable per-output-channel bit-width configuration), soft and hard phase."""
     x = synth.weight(shape[0], shape[1], 5)
     up, low = synth.lwc_factors(shape[0], 6)
     nb = synth.mix_bits(shape[0], 3.0, 7)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development check: do the bench's HIP graphs (this library's kernels only) keep producing the eager results
 when small eager kernels are launched between replays?  (A graph of a whole PyTorch training step did not on
-this ROCm build; see the calibration-loop notes in DESIGN.md.)  Prints the number of steps whose packed
+this ROCm build: with the optimizer's small eager kernels between replays it turned wrong after a few steps.)  Prints the number of steps whose packed
 LWC gradient vector differs from the eager one."""
 import os
 import sys
