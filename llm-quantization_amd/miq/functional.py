@@ -705,7 +705,10 @@ class ActCalibFQ(torch.autograd.Function):
         x = x.contiguous()
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
-        k = _tensor_fold(x2.shape[0], C, layout) if x2.numel() else 1
+        synced = dp is not None and dp.active and dp.sync_stats
+        # (with statistics synchronised across ranks the vectors that are all-reduced keep the caller's width, whatever
+        # the local row count)
+        k = _tensor_fold(x2.shape[0], C, layout) if (x2.numel() and not synced) else 1
         if k > 1:
             x2 = x2.reshape(-1, C * k)
             layout = ClusterLayout.get(None, C * k, x.device)
@@ -713,7 +716,7 @@ class ActCalibFQ(torch.autograd.Function):
                 cached_min = cached_min[:1].expand(C * k).contiguous()
                 cached_max = cached_max[:1].expand(C * k).contiguous()
         ctx.dp = dp
-        if dp is not None and dp.active and dp.sync_stats:
+        if synced:
             st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max, dp=dp)
             out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
         else:
