@@ -331,6 +331,19 @@ int miq_rotary(const void* x, const void* cos, const void* sin, void* out, int64
  */
 int miq_truncate_inplace(void* const* ptrs, const int64_t* sizes, int n, float threshold, int dtype, void* stream);
 
+/*
+ * The calibration loss loss_func(fp_out, quant_out) = torch.nn.MSELoss() (quantize/omniquant.py:339, 511-513) on
+ * tensors of `dtype` without the fp32 copies autocast makes of fp16 operands:
+ *   miq_mse_fwd  out[0] = mean((float(a) - float(b))^2); workspace: miq_mse_workspace() floats
+ *   miq_mse_bwd  da = dtype(((2/n) * (a - b)) * grad_loss[0]), db = the same with (b - a): ATen's
+ *                mse_loss_backward in fp32 followed by the cast back that autocast's backward applies
+ *                (bit-identical gradients); grad_loss is a DEVICE scalar; da / db may each be NULL.
+ * a, b contiguous with n elements, 16-byte aligned.
+ */
+int64_t miq_mse_workspace(void);
+int miq_mse_fwd(const void* a, const void* b, float* out, float* workspace, int64_t n, int dtype, void* stream);
+int miq_mse_bwd(const void* a, const void* b, const float* grad_loss, void* da, void* db, int64_t n, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

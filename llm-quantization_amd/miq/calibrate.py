@@ -27,6 +27,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import functional as MF
 from . import reorder_utils as R
 from .dist import DPContext, allreduce_mean_grads, broadcast_from, owner_of, shard_range
 from .int_linear import QuantLinear
@@ -274,7 +275,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
 
     dtype = torch.float32 if (cfg.deactive_amp and cfg.epochs > 0) else torch.float16
     traincast = (lambda: torch.autocast("cuda", dtype=torch.float16)) if use_amp else nullcontext
-    loss_func = nn.MSELoss()
+    loss_func = MF.mse_loss  # nn.MSELoss(); fp16 operands under autocast take the kernel path
     mask_batch = None
     if attention_mask is not None:
         mask_batch = attention_mask.repeat(cfg.batch_size, 1, 1, 1)

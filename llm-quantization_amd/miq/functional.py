@@ -539,6 +539,51 @@ class RMSNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
+FUSED_MSE = True  # module-wide switch of mse_loss's kernel path (A/B timing)
+
+
+def mse_supported(a, b) -> bool:
+    return bool(FUSED_MSE and a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float16 and a.shape == b.shape
+                and a.numel() > 0 and torch.is_autocast_enabled())
+
+
+class MSELossHalf(torch.autograd.Function):
+    """torch.nn.functional.mse_loss(a, b) for fp16 tensors under autocast (which evaluates it in fp32): fp32 scalar
+    from one streaming pass over the fp16 tensors; gradients bit-identical to ATen's (miq_mse_fwd / miq_mse_bwd)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        dev = L.check_gpu(a, b)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.lib().miq_mse_workspace()), dtype=torch.float32, device=dev)
+        with L.on_device(dev):
+            L.call("miq_mse_fwd", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(ws), L.i64(a.numel()), L.i32(L.dtype_code(a)), L.stream_of(a))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        need_a, need_b = ctx.needs_input_grad
+        if not (need_a or need_b):
+            return None, None
+        g = g.to(torch.float32).contiguous()
+        da = torch.empty_like(a) if need_a else None
+        db = torch.empty_like(b) if need_b else None
+        with L.on_device(a.device):
+            L.call("miq_mse_bwd", L.ptr(a), L.ptr(b), L.ptr(g), L.ptr(da), L.ptr(db), L.i64(a.numel()), L.i32(L.dtype_code(a)),
+                   L.stream_of(a))
+        return da, db
+
+
+def mse_loss(a, b):
+    """The calibration loss: MSELoss()(a, b) (reference quantize/omniquant.py:339, 511-513)."""
+    if mse_supported(a, b):
+        return MSELossHalf.apply(a, b)
+    return torch.nn.functional.mse_loss(a, b)
+
+
 def truncate_inplace_(tensors, threshold: float = 1e-2):
     """x[|x| < threshold] = sign(x) * threshold, in place, for a list of contiguous GPU tensors of one dtype
     (miq_truncate_inplace: one launch per 16 tensors)."""

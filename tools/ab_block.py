@@ -21,7 +21,7 @@ from miq.blocks import _BlockBase, _Rotary  # noqa: E402
 from miq.int_linear import QuantLinear  # noqa: E402
 from miq.omni_norm import OmniLlamaRMSNorm  # noqa: E402
 
-SWITCHES = {"half_weights": (_BlockBase, "half_weights"), "tensor_fold": (functional, "TENSOR_FOLD"), "rotary": (_Rotary, "fused"), "bias_grad": (QuantLinear, "fused_bias_grad"), "rmsnorm": (OmniLlamaRMSNorm, "fused")}
+SWITCHES = {"fused_mse": (functional, "FUSED_MSE"), "half_weights": (_BlockBase, "half_weights"), "tensor_fold": (functional, "TENSOR_FOLD"), "rotary": (_Rotary, "fused"), "bias_grad": (QuantLinear, "fused_bias_grad"), "rmsnorm": (OmniLlamaRMSNorm, "fused")}
 
 
 def one_run_ms(model, amp):
