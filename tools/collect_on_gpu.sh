@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects one measurement directory on the GPU box (run from the repository root):
-#   bash tools/collect_on_gpu.sh gpurun_out/r01_g
+#   bash tools/collect_on_gpu.sh gpurun_out/r01_h
 # bench line, kernel trace of the bench, the two PMC passes (own runs, no tracing), operator families, the larger
 # block shapes, and a kernel trace of the Llama-2-7B fp16 calibration step.  Every GPU step has its own time limit
 # and the script stops at the first failure.  tools/collect_profiles.py installs the directory into profiles/.

@@ -3,7 +3,7 @@
 into profiles/: bench line, kernel-trace summary, the library's rows of the two PMC passes, the per-kernel
 traffic summary, the per-family traffic file that bench.py reads, and the family table.
 
-usage: collect_profiles.py <gpurun_out/dir> <tag, e.g. r01_g>
+usage: collect_profiles.py <gpurun_out/dir> <tag, e.g. r01_h>
 """
 import csv
 import glob

@@ -98,13 +98,13 @@ def main():
              "library's kernels 31 % (LET-fused weight quantizer 13.1 %, activation quantizers 8.1 %, fused attention-score pass 4.8 %, "
              "RMSNorm / rotary / bias-gradient column sums / truncate 4.5 %, plain weight quantizer 0.7 %), dtype casts / copies / cat "
              "6.5 %, other PyTorch elementwise kernels (SwiGLU, residual adds, loss, small LET vector ops) 8 %, reductions 1 %, "
-             "optimizer 0.7 %; 4200 launches in the run against 4720 before the launch-count work.  "
+             "optimizer 0.7 %; 4150 launches in the run against 4720 before the launch-count work.  "
              "History of the fp16 step on the same shape: 13.2 ms with LET in PyTorch ops → 12.3 ms with the LET-fused kernels → 11.4 ms with "
              "the two-kernel LET backward and fp16 weight output → 9.8 ms without the per-step host round trips (loss / norm trace on the "
-             "device, `truncate_number` as `torch.where`) → 7.8 ms with the fused attention-score pass → 6.6–6.9 ms with the fused RMSNorm, "
+             "device, `truncate_number` as `torch.where`) → 7.8 ms with the fused attention-score pass → 6.4–6.6 ms with the fused RMSNorm, "
              "the column-sum bias gradient, the rotary kernel, narrow per-tensor slabs folded to wide rows, the per-cluster parameter "
              "kernels sliced over several blocks, the reciprocal-product LET backward, no materialised zero gradients, the "
-             "batched truncate kernel and in-kernel rounding of the bias gradient (boxes differ by ±3 %; "
+             "batched truncate kernel, in-kernel rounding of the bias gradient and the fused loss (boxes differ by ±3 %; "
              f"`{tag}_ab_block.json` holds same-box differences).  Llama-2-70B (no LET) under fp16 autocast: 17.9 → 15.3 ms per step and "
              "11.6 → 9.4 GiB since plain fp32 weights are quantized straight into fp16.\n")
     L.append("LET-fused kernels alone (`tools/bench_let.py`, [4096,4096] fp32): forward 34–36 µs (3.8 TB/s over read W + write Wq), backward 66 µs "
