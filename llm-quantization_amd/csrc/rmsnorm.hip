@@ -24,6 +24,7 @@ struct RmsArgs {
 template <typename TX, int VEC, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
 k_rmsnorm_fwd(RmsArgs a, TX* __restrict__ out, float* __restrict__ rstd_out) {
+    static_assert(VEC == 4, "the weight / bias vectors are read as float4");
     __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
@@ -48,11 +49,15 @@ k_rmsnorm_fwd(RmsArgs a, TX* __restrict__ out, float* __restrict__ rstd_out) {
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
         const long long c0 = x.offset(k);
+        // VEC == 4: one 16-byte load per vector and pack (the entry point checks the alignment)
+        const float4 w4 = *reinterpret_cast<const float4*>(a.weight + c0);
+        const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
         Pack<TX, VEC> o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float y = a.weight[c0 + e] * (to_f<TX>(x.v[k].e[e]) * rstd);
-            if (a.bias) y += a.bias[c0 + e];
+            float y = wv[e] * (to_f<TX>(x.v[k].e[e]) * rstd);
+            if (a.bias) y += bv[e];
             o.e[e] = from_f<TX>(y);
         }
         st_pack<TX, VEC>(out + row * a.C + c0, o);
@@ -62,6 +67,7 @@ k_rmsnorm_fwd(RmsArgs a, TX* __restrict__ out, float* __restrict__ rstd_out) {
 template <typename TX, int VEC, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
 k_rmsnorm_bwd_rows(RmsArgs a, const TX* __restrict__ gy, const float* __restrict__ rstd, TX* __restrict__ dx) {
+    static_assert(VEC == 4, "the weight vector is read as float4");
     __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
@@ -77,9 +83,11 @@ k_rmsnorm_bwd_rows(RmsArgs a, const TX* __restrict__ gy, const float* __restrict
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
         const long long c0 = x.offset(k);
+        const float4 w4 = *reinterpret_cast<const float4*>(a.weight + c0);
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            du[k][e] = to_f<TX>(g.v[k].e[e]) * a.weight[c0 + e];
+            du[k][e] = to_f<TX>(g.v[k].e[e]) * wv[e];
             dot[0] += du[k][e] * (to_f<TX>(x.v[k].e[e]) * rs);
         }
     }
@@ -224,7 +232,8 @@ extern "C" int miq_rmsnorm_fwd(const void* x, const float* weight, const float* 
     MIQ_CHECK_ARG(C % 4 == 0 && C / 4 <= kRowMaxPacks, "miq_rmsnorm_fwd: C=%lld must be a multiple of 4 and at most %d", (long long)C,
                   4 * kRowMaxPacks);
     MIQ_CHECK_ARG(dtype == MIQ_F32 || dtype == MIQ_F16, "miq_rmsnorm_fwd: unsupported dtype %d", dtype);
-    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(out), "miq_rmsnorm_fwd: x / out must be 16-byte aligned");
+    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(out) && is_aligned16(weight) && is_aligned16(bias),
+                  "miq_rmsnorm_fwd: x / out / weight / bias must be 16-byte aligned");
     RmsArgs a{x, weight, bias, eps, R, (int)C};
     if (dtype == MIQ_F32) rms_fwd_launch<float>(a, out, rstd_out, (hipStream_t)stream);
     else rms_fwd_launch<__half>(a, out, rstd_out, (hipStream_t)stream);
@@ -240,7 +249,8 @@ extern "C" int miq_rmsnorm_bwd(const void* grad_out, const void* x, const float*
     MIQ_CHECK_ARG(C % 4 == 0 && C / 4 <= kRowMaxPacks, "miq_rmsnorm_bwd: C=%lld must be a multiple of 4 and at most %d", (long long)C,
                   4 * kRowMaxPacks);
     MIQ_CHECK_ARG(dtype == MIQ_F32 || dtype == MIQ_F16, "miq_rmsnorm_bwd: unsupported dtype %d", dtype);
-    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(grad_out) && is_aligned16(dx), "miq_rmsnorm_bwd: x / grad_out / dx must be 16-byte aligned");
+    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(grad_out) && is_aligned16(dx) && is_aligned16(weight),
+                  "miq_rmsnorm_bwd: x / grad_out / dx / weight must be 16-byte aligned");
     MIQ_CHECK_ARG((!d_weight && !d_bias) || (workspace && is_aligned16(workspace)), "miq_rmsnorm_bwd: workspace required for d_weight / d_bias");
     RmsArgs a{x, weight, nullptr, 0.f, R, (int)C};
     if (dtype == MIQ_F32) rms_bwd_launch<float>(a, grad_out, rstd, dx, d_weight, d_bias, workspace, (hipStream_t)stream);

@@ -492,8 +492,9 @@ def rmsnorm_supported(x, weight, bias) -> bool:
     C = x.shape[-1]
     ok = x.is_cuda and x.dtype in (torch.float16, torch.float32) and C % 4 == 0 and 0 < C <= 16384 and x.numel() > 0
     for t in (weight, bias):
-        ok = ok and (t is None or (t.is_cuda and t.dtype in (torch.float16, torch.float32) and t.numel() == C))
-    return bool(ok and weight is not None)
+        ok = ok and (t is None or (t.is_cuda and t.dtype in (torch.float16, torch.float32) and t.numel() == C
+                                   and t.data_ptr() % 16 == 0))
+    return bool(ok and weight is not None and x.data_ptr() % 16 == 0)
 
 
 class RMSNorm(torch.autograd.Function):
