@@ -859,8 +859,8 @@ class LetRowFQ(torch.autograd.Function):
         w, cs, rs, sh, up, low = ctx.saved_tensors
         rs_div, n_bits, symmetric = ctx.cfg
         need = ctx.needs_input_grad
-        if g is None and g_wshift is None:
-            return (None,) * 10
+        if (g is None and g_wshift is None) or not any(need[i] for i in (1, 2, 4, 5, 6)):
+            return (None,) * 10  # nothing was used downstream, or nothing trainable went in
         if g is None:  # only w @ shift was used
             g = torch.zeros(w.shape, dtype=torch.float16 if ctx.half_out else w.dtype, device=w.device)
         if g_wshift is None and sh is not None:
