@@ -89,3 +89,14 @@ def test_quant_linear_uses_it_only_for_a_trained_bias():
     q.fused_bias_grad = True
     q.temp_bias = q.bias  # a buffer: nothing to train
     assert q(x).grad_fn is None
+
+
+def test_col_sum_is_linear_at_block_size():
+    """[2048, 11008] (the widest bias gradient of a Llama-2-7B block): col_sum(a + b) = col_sum(a) + col_sum(b) and
+    col_sum(2a) = 2 col_sum(a) to fp32 summation accuracy."""
+    g = torch.Generator(device=DEV).manual_seed(8)
+    a = torch.randn(2048, 11008, generator=g, device=DEV)
+    b = torch.randn(2048, 11008, generator=g, device=DEV)
+    sa, sb = F.col_sum(a), F.col_sum(b)
+    assert torch.allclose(F.col_sum(a + b), sa + sb, rtol=1e-4, atol=2e-3)
+    assert torch.equal(F.col_sum(2 * a), 2 * sa)

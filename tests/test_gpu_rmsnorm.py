@@ -111,3 +111,15 @@ def test_unsupported_inputs_are_declined():
     assert not F.rmsnorm_supported(torch.zeros(4, 8, device=DEV, dtype=torch.bfloat16), torch.ones(8, device=DEV), None)
     assert not F.rmsnorm_supported(torch.zeros(4, 8, device=DEV), None, None)
     assert not F.rmsnorm_supported(torch.zeros(0, 8, device=DEV), torch.ones(8, device=DEV), None)
+
+
+def test_unit_rms_at_block_size():
+    """[2048, 4096] fp16 hidden states with unit weight and no bias: every output row has root mean square
+    sqrt(v / (v + eps)) with v the mean square of the input row (1 up to eps), to fp16 rounding, whatever the scale
+    of the input row."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.randn(2048, 4096, generator=g, device=DEV) * torch.logspace(-2, 2, 2048, device=DEV)[:, None]).half()
+    y = F.RMSNorm.apply(x, torch.ones(4096, device=DEV), None, 1e-6)
+    rms = y.float().pow(2).mean(-1).sqrt()
+    v = x.float().pow(2).mean(-1)
+    assert (rms - torch.sqrt(v / (v + 1e-6))).abs().max().item() <= 1e-3

@@ -71,3 +71,19 @@ def test_unsupported_layouts_are_declined():
     assert not F.rotary_supported(x[..., ::2], cos, sin)                      # strided last dimension
     assert not F.rotary_supported(x.float(), cos, sin)                        # table dtype differs
     assert not F.rotary_supported(torch.zeros(1, 2, 4, 24, device=DEV, dtype=torch.float16), *tables(1, 4, 24, torch.float16, 1))
+
+
+def test_round_trip_at_block_size():
+    """Llama-2-7B query shape [1, 32, 2048, 128] fp16 with the module's own tables: the backward kernel applies the
+    transposed (= inverse) rotation, so forward followed by backward returns the input to fp16 rounding, and the
+    rotation keeps the norm of every head vector."""
+    B, H, T, D = 1, 32, 2048, 128
+    rot = _Rotary(D)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(B, T, H * D, generator=g, device=DEV).half().view(B, T, H, D).transpose(1, 2)
+    cos, sin = rot.tables(torch.arange(T, device=DEV).unsqueeze(0), x.device, x.dtype)
+    y = F.RotaryEmb.apply(x, cos, sin)
+    back = torch.empty((B, T, H, D), dtype=x.dtype, device=DEV).transpose(1, 2)
+    F._rotary_call(y, cos, sin, back, True)
+    assert (back.float() - x.float()).abs().max().item() <= 1e-2
+    assert torch.allclose(y.float().norm(dim=-1), x.float().norm(dim=-1), rtol=2e-3)
