@@ -161,6 +161,24 @@ int miq_act_calib_quant_fwd(const void* x, const void* cached_min, const void* c
                             void* zp_out, void* rzp_out, int64_t R, int64_t C, int dtype, void* stream);
 
 /*
+ * miq_act_calib_quant_fwd for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and
+ * results as miq_act_calib_quant_fwd; the partial statistics live in a device array inside the library
+ * (miq_act_static_capacity() floats = 8 MiB on every GPU the library runs on, held until the process ends)
+ * instead of a caller workspace, and the call makes no hipMalloc / hipFree.  Slabs whose
+ * miq_act_workspace(R, C, dtype) exceeds the capacity are rejected with -22.  chan_min_out / chan_max_out:
+ * optional fp32 [C], receive the per-channel statistics before the cluster merge (the chan_min / chan_max inputs
+ * of miq_colquant_bwd).  The tensors' device must be the current device.  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream are safe.
+ */
+int64_t miq_act_static_capacity(void);
+int miq_act_calib_quant_fwd_static(const void* x, const void* cached_min, const void* cached_max, int metric,
+                                   const int* starts, int n_clusters, int64_t covered, int n_bits, void* out,
+                                   void* codes_out, void* cmin_out, void* cmax_out, void* scale_out, void* zp_out,
+                                   void* rzp_out, float* chan_min_out, float* chan_max_out, int64_t R, int64_t C,
+                                   int dtype, void* stream);
+
+/*
  * RPTQ channel reorder: out[r, c] = x[r, idx[c]] (torch.index_select on the last axis, as in
  * OmniLayerNorm.forward, quantize/omni_norm.py:36-40).  Rows are staged through LDS so that both
  * the global loads and the global stores stay coalesced.  idx: int32 [C], entries in [0, C).

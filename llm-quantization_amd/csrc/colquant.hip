@@ -9,6 +9,7 @@
 // Semantics: UniformAffineQuantizer.per_cluster_minmax_calibration / per_tensor_minmax_calibration /
 // calibration / fake_quant (reference quantize/quantizer.py:157-238,99-121) and the index_select in
 // OmniLayerNorm.forward (quantize/omni_norm.py:36-40).
+#include <mutex>
 #include <type_traits>
 #include "miq_common.h"
 
@@ -461,6 +462,74 @@ extern "C" int miq_act_calib_quant_fwd(const void* x, const void* cached_min, co
                            cmin_out, cmax_out, scale_out, zp_out, rzp_out, dtype, stream);
     if (rc) return rc;
     return miq_colquant_fwd(x, scale_out, rzp_out, out, codes_out, R, C, n_bits, dtype, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same call for callers that cannot allocate (HIP graph capture, serving loops): the partial
+// statistics live in a file-scope device array instead of a caller-provided workspace.  Every GPU
+// the library runs on holds its own copy of the array at its own address; host code only ever
+// uses the per-device address looked up with hipGetSymbolAddress, never the array's name.
+// ---------------------------------------------------------------------------------------------
+constexpr int64_t kStaticScratchFloats = 2ll << 20;  // 8 MiB per GPU
+static __device__ __align__(256) float scratch[kStaticScratchFloats];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static float* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each GPU, looked up once
+
+// device address of this GPU's copy of `scratch` (the current device must be the tensors' device)
+static int static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    MIQ_CHECK_ARG(e == hipSuccess && dev >= 0 && dev < kMaxDevices, "miq_act_calib_quant_fwd_static: no current device (%s)",
+                  hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            miq_set_error("miq_act_calib_quant_fwd_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return -5;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int64_t miq_act_static_capacity(void) { return kStaticScratchFloats; }
+
+extern "C" int miq_act_calib_quant_fwd_static(const void* x, const void* cached_min, const void* cached_max, int metric,
+                                              const int* starts, int n_clusters, int64_t covered, int n_bits,
+                                              void* out, void* codes_out, void* cmin_out, void* cmax_out, void* scale_out,
+                                              void* zp_out, void* rzp_out, float* chan_min_out, float* chan_max_out,
+                                              int64_t R, int64_t C, int dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(R > 0 && C > 0 && C < (1ll << 31), "miq_act_calib_quant_fwd_static: bad shape (R=%lld C=%lld)", (long long)R, (long long)C);
+    const int64_t need = miq_act_workspace(R, C, dtype);
+    MIQ_CHECK_ARG(need <= kStaticScratchFloats,
+                  "miq_act_calib_quant_fwd_static: a [%lld, %lld] slab needs %lld floats of scratch, the static buffer holds %lld; "
+                  "use miq_act_calib_quant_fwd with a caller workspace", (long long)R, (long long)C, (long long)need,
+                  (long long)kStaticScratchFloats);
+    MIQ_CHECK_ARG((chan_min_out == nullptr) == (chan_max_out == nullptr), "miq_act_calib_quant_fwd_static: chan_min_out/chan_max_out must come together");
+    float* ws = nullptr;
+    int rc = static_scratch(&ws);
+    if (rc) return rc;
+    rc = miq_act_calib_quant_fwd(x, cached_min, cached_max, metric, starts, n_clusters, covered, n_bits, ws, out, codes_out,
+                                 cmin_out, cmax_out, scale_out, zp_out, rzp_out, R, C, dtype, stream);
+    if (rc) return rc;
+    if (chan_min_out) {
+        const int nchunk = miq_colstat_chunks(R, C, dtype);
+        const size_t bytes = (size_t)C * sizeof(float);
+        hipError_t e = hipMemcpyAsync(chan_min_out, ws + (int64_t)nchunk * C, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(chan_max_out, ws + (int64_t)(2 * nchunk + 1) * C, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) {
+            miq_set_error("miq_act_calib_quant_fwd_static: copy of the per-channel statistics failed: %s", hipGetErrorString(e));
+            return -5;
+        }
+    }
+    return 0;
 }
 
 extern "C" int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int64_t C, int dtype, void* stream) {
