@@ -161,6 +161,40 @@ int miq_act_calib_quant_fwd(const void* x, const void* cached_min, const void* c
                             void* zp_out, void* rzp_out, int64_t R, int64_t C, int dtype, void* stream);
 
 /*
+ * The calibrating static quantizer with FRESH statistics (no cached values: what every forward of a training step
+ * sees, because omniquant() frees the cached statistics after each optimizer step, quantize/omniquant.py:530-535) for
+ * up to 8 slabs of one shape, dtype and cluster layout per call — the q/k/v projections' inputs and outputs and the
+ * gate/up inputs of a decoder block are quantized side by side (models/int_llama_layer.py:110-116, :139-154).
+ * Forward: two launches (statistics, quantize) instead of four.  The row-chunk blocks of the statistics kernel merge
+ * their per-cluster minima / maxima with integer atomic maxima on order-preserving keys (exact, order independent), the
+ * quantize kernel derives scale / zero point from that table itself.  Results are bit-identical to
+ * miq_act_calib_quant_fwd with cached_min == NULL.
+ *   x, out        host arrays of n device pointers to [R, C] slabs; codes_out: NULL or n pointers (entries may be NULL)
+ *   stats_out     n device pointers to [5, C] blocks of `dtype`: merged min, merged max, scale, clamped zero point,
+ *                 rounded zero point (rows 0 / 1 are what the quantizer caches, rows 2 / 4 its scale / round_zero_point)
+ *   cluster_size  > 0: n_clusters clusters of that many channels each (cluster_size * n_clusters == covered);
+ *                 0: unequal clusters, described by slot_of [C] int32 on the device: cluster id for a channel inside a
+ *                 cluster, n_clusters + (c - covered) for a channel c >= covered (those keep per-channel statistics)
+ *   workspace     miq_act_fresh_workspace(n, C, n_clusters, covered) BYTES, 128-byte aligned, zero-filled once before
+ *                 its first use and afterwards only passed to this function (it carries a call counter; 2^32 calls).
+ *                 Calls that share a workspace must be ordered on one stream.
+ * Backward (what autograd derives, as miq_colquant_bwd): stats = the [5, C] blocks of the forward; the extreme elements
+ * are found by comparing with the merged statistics.  With equal clusters of at most 1024 channels that cover every
+ * channel the chunk fold, the shares and the (usually sparse) correction run in one launch (3 launches in all, the
+ * last one a no-op unless a cluster has mass ties), otherwise in the four of miq_colquant_bwd; same bits either way.
+ *   starts        [n_clusters + 1] int32 prefix sums of the cluster sizes on the device
+ *   workspace     miq_act_fresh_bwd_workspace(n, R, C, dtype) BYTES, 16-byte aligned, no initialisation needed
+ */
+int64_t miq_act_fresh_workspace(int n, int64_t C, int n_clusters, int64_t covered);
+int miq_act_fresh_quant_fwd(int n, const void* const* x, int64_t cluster_size, const int* slot_of, int n_clusters,
+                            int64_t covered, int n_bits, void* workspace, void* const* out, void* const* codes_out,
+                            void* const* stats_out, int64_t R, int64_t C, int dtype, void* stream);
+int64_t miq_act_fresh_bwd_workspace(int n, int64_t R, int64_t C, int dtype);
+int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const void* const* x, const void* const* stats,
+                            int64_t cluster_size, const int* starts, int n_clusters, int64_t covered, int n_bits,
+                            void* workspace, void* const* dx, int64_t R, int64_t C, int dtype, void* stream);
+
+/*
  * miq_act_calib_quant_fwd for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and
  * results as miq_act_calib_quant_fwd; the partial statistics live in a device array inside the library

@@ -261,6 +261,288 @@ k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fresh statistics (no cached values: every call of a training step): two kernels instead of four.
+//
+// The statistics of a cluster are a minimum / maximum over all of its elements, which is associative and
+// commutative, so the row-chunk blocks combine them with integer atomic maxima on order-preserving keys: the result
+// does not depend on the arrival order and equals the fold of per-channel partials bit for bit.  A "slot" is one
+// statistics unit: cluster k for the channels of cluster k, n_clusters + (c - covered) for a channel c outside every
+// cluster; slot_of[c] maps channels to slots.  The slot table in the workspace is never cleared: every 64-bit word
+// carries, above the 32-bit key, a call number that grows with every call, so a word written by an earlier call
+// always loses against the current one (the table only has to be zero when it is first used).
+//   ws[0]  call number of the last completed call  (read by the statistics kernel, written by the quantize kernel)
+//   ws[1]  call number of the call in flight       (written by the statistics kernel, read by the quantize kernel)
+//   ws[16 + slab * table_words + 16 * (slot * nrep + rep) + {0, 1}]   {min, max} of replica rep of a slot of a slab
+//                                                                      (one 128-byte line each)
+// One pair of counters serves every slab and every layout the workspace is used with: whatever an earlier call left
+// anywhere in the table carries a smaller call number.
+// Replicas spread the atomics of a slot that many blocks feed (one cluster spanning all channels: every block).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+
+// order-preserving key of a float for an unsigned maximum; NaN maps to the largest key (it wins, like torch.amax)
+__device__ __forceinline__ unsigned max_key(float f) {
+    if (f != f) return 0xFFFFFFFFu;
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float max_key_value(unsigned k) {
+    if (k == 0xFFFFFFFFu) return __builtin_nanf("");
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+// the same for a minimum: the complemented key, NaN again the largest
+__device__ __forceinline__ unsigned min_key(float f) { return (f != f) ? 0xFFFFFFFFu : ~max_key(f); }
+__device__ __forceinline__ float min_key_value(unsigned k) {
+    if (k == 0xFFFFFFFFu) return __builtin_nanf("");
+    return max_key_value(~k);
+}
+
+// slot of channel c: by arithmetic for equal-sized clusters (csize > 0), through the map otherwise
+struct SlotMap {
+    const int* slot_of;  // [C] or nullptr when csize > 0
+    int csize;           // size of every cluster, or 0
+    int covered;         // channels that belong to a cluster
+    int ncl;
+    __device__ __forceinline__ int operator()(long long c) const {
+        if (csize > 0) return c < covered ? (int)(c / csize) : ncl + (int)(c - covered);
+        return slot_of[c];
+    }
+};
+constexpr int kSlotStride = 16;  // 64-bit words per slot replica: one 128-byte line each, so that the atomics of
+                                 // different slots (and replicas) are served by different cache lines
+constexpr int kMaxSlabs = 8;     // slabs of one shape per launch (grid.z)
+struct SlabPtrs { const void* p[kMaxSlabs]; };
+struct SlabOuts { void* p[kMaxSlabs]; };
+
+// Statistics pass.  Block = 4 waves; lane l owns one 16-byte pack of channels, wave w the rows r0 + w, r0 + w + 4, ...
+// of the block's row chunk with DEPTH rows in flight (every wave-load is one contiguous 1 KiB segment).  blockIdx.z
+// selects the slab; slab i uses the table at ws + 16 + i * ws_stride.
+template <typename T, int VEC, int DEPTH>
+__global__ void __launch_bounds__(256)
+k_colstat_slots(SlabPtrs xs, long long R, int C, int rows_per_chunk, SlotMap sm, u64* ws_base, long long ws_stride, int nrep) {
+    __shared__ float smin[3][64 * VEC];
+    __shared__ float smax[3][64 * VEC];
+    const T* __restrict__ x = static_cast<const T*>(xs.p[blockIdx.z]);
+    u64* ws = ws_base;  // the two call counters, shared by all slabs
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    const bool valid = col0 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float mn[VEC], mx[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mn[e] = __builtin_inff(); mx[e] = -__builtin_inff(); }
+    if (valid) {
+        const T* p = x + col0;
+        long long r = r0 + w;
+        for (; r + (DEPTH - 1) * 4 < r1; r += DEPTH * 4) {
+            Pack<T, VEC> a[DEPTH];
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) a[u] = ld_pack<T, VEC>(p + (r + u * 4) * C);
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float f = to_f<T>(a[u].e[e]);
+                    mn[e] = nmin(mn[e], f);
+                    mx[e] = nmax(mx[e], f);
+                }
+        }
+        for (; r < r1; r += 4) {
+            Pack<T, VEC> a = ld_pack<T, VEC>(p + r * C);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float f = to_f<T>(a.e[e]);
+                mn[e] = nmin(mn[e], f);
+                mx[e] = nmax(mx[e], f);
+            }
+        }
+    }
+    unsigned tag = 0;
+    if (w == 0) tag = (unsigned)ws[0] + 1u;  // requested before the exchange below, used after it
+    if (w > 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            smin[w - 1][lane * VEC + e] = mn[e];
+            smax[w - 1][lane * VEC + e] = mx[e];
+        }
+    }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            mn[e] = nmin(mn[e], smin[u][lane * VEC + e]);
+            mx[e] = nmax(mx[e], smax[u][lane * VEC + e]);
+        }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) ws[1] = tag;
+    u64* const table = ws + kSlotStride + blockIdx.z * ws_stride;
+    const int rep = blockIdx.y % nrep;
+    const u64 hi = (u64)tag << 32;
+    auto publish = [&](int slot, float lo_v, float hi_v) {
+        u64* q = table + ((long long)slot * nrep + rep) * kSlotStride;
+        atomicMax(q, hi | min_key(lo_v));
+        atomicMax(q + 1, hi | max_key(hi_v));
+    };
+    // A lane whose channels all belong to one slot first joins its neighbours of the same slot (slots are contiguous
+    // channel ranges, so equal slots sit in consecutive lanes: a segmented scan); the last lane of every run issues the
+    // two atomics.  A lane that straddles slots publishes its channels one by one.
+    int sl[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sl[e] = valid ? sm(col0 + e) : -1;
+    bool uniform = valid;
+#pragma unroll
+    for (int e = 1; e < VEC; ++e) uniform = uniform && (sl[e] == sl[0]);
+    float lo_v = mn[0], hi_v = mx[0];
+#pragma unroll
+    for (int e = 1; e < VEC; ++e) { lo_v = nmin(lo_v, mn[e]); hi_v = nmax(hi_v, mx[e]); }
+    const int key = uniform ? sl[0] : -2 - lane;  // unique negative key: joins nobody
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int k2 = __shfl_up(key, o);
+        const float a = __shfl_up(lo_v, o), b = __shfl_up(hi_v, o);
+        if (lane >= o && k2 == key) { lo_v = nmin(lo_v, a); hi_v = nmax(hi_v, b); }
+    }
+    const int knext = __shfl_down(key, 1);
+    if (uniform) {
+        if (lane == 63 || knext != key) publish(key, lo_v, hi_v);
+    } else if (valid) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) publish(sl[e], mn[e], mx[e]);
+    }
+}
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// the {min, max} words of the NREP replicas of a slot, requested together; finish() folds the ones of the current call
+// and derives the reference's scale / zero point
+template <typename T, int NREP>
+struct SlotParams {
+    u64x2 raw[NREP];
+    float mn, mx, s, zp, z, rs;
+    __device__ __forceinline__ void request(const u64* table, int slot) {
+#pragma unroll
+        for (int rep = 0; rep < NREP; ++rep)
+            raw[rep] = *reinterpret_cast<const u64x2*>(table + ((long long)slot * NREP + rep) * kSlotStride);
+    }
+    __device__ __forceinline__ void finish(unsigned tag, float qmax) {
+        unsigned klo = 0, khi = 0;  // keys of real values are never 0
+#pragma unroll
+        for (int rep = 0; rep < NREP; ++rep) {
+            if ((unsigned)(raw[rep].x >> 32) == tag && (unsigned)raw[rep].x > klo) klo = (unsigned)raw[rep].x;
+            if ((unsigned)(raw[rep].y >> 32) == tag && (unsigned)raw[rep].y > khi) khi = (unsigned)raw[rep].y;
+        }
+        mn = min_key_value(klo);
+        mx = max_key_value(khi);
+        s = clampf(rnd<T>(rnd<T>(mx - mn) / qmax), rnd<T>(kClipLo), kClipHi);
+        zp = clampf(rnd<T>(-mn / s), -kClipHi, kClipHi);
+        z = rintf(zp);
+        rs = 1.0f / s;
+    }
+};
+
+// quantize-dequantize with the parameters derived from the slot table; the blocks of row chunk 0 also write the
+// [5, C] vectors the caller keeps (merged min, merged max, scale, zero point, rounded zero point).  Lane / wave / row
+// mapping of k_colstat_slots.  UNIFORM: every lane's pack lies inside one slot (equal cluster sizes that are multiples
+// of VEC, no channel outside a cluster): one parameter set per lane.  The first rows are requested between the table
+// loads and their use, so the parameter chain costs no extra memory round trip.
+template <typename T, int VEC, int DEPTH, int NREP, bool UNIFORM>
+__global__ void __launch_bounds__(256)
+k_colquant_slots(SlabPtrs xs, SlotMap sm, u64* ws_base, long long ws_stride, SlabOuts outs, SlabOuts codes_tab, SlabOuts vecs,
+                 long long R, int C, int rows_per_chunk, float qmax) {
+    constexpr int NP = UNIFORM ? 1 : VEC;  // parameter sets per lane
+    const T* __restrict__ x = static_cast<const T*>(xs.p[blockIdx.z]);
+    T* __restrict__ out = static_cast<T*>(outs.p[blockIdx.z]);
+    uint8_t* __restrict__ codes = static_cast<uint8_t*>(codes_tab.p[blockIdx.z]);
+    T* __restrict__ vec = static_cast<T*>(vecs.p[blockIdx.z]);
+    u64* ws = ws_base;
+    const u64* table = ws + kSlotStride + blockIdx.z * ws_stride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    if (col0 >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    const unsigned tag = (unsigned)ws[1];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[0] = tag;
+    SlotParams<T, NREP> sp[NP];
+    // (general form: a lane whose channels share one slot, i.e. nearly every lane, still asks for one parameter set)
+    int sl[NP];
+    bool lane_uniform = true;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        sl[k] = sm(col0 + k);
+        lane_uniform = lane_uniform && sl[k] == sl[0];
+    }
+    if (lane_uniform) {
+        sp[0].request(table, sl[0]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sp[k].request(table, sl[k]);
+    }
+    long long r = r0 + w;
+    Pack<T, VEC> first[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)
+        if (r + 4 * u < r1) first[u] = ld_pack<T, VEC>(x + (r + 4 * u) * C + col0);
+    float s[NP], z[NP], rs[NP];
+    bool ok = true;
+    {
+        Pack<T, VEC> v0, v1, v2, v3, v4;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (k == 0 || !lane_uniform) sp[k].finish(tag, qmax);
+            else sp[k] = sp[0];
+            s[k] = sp[k].s; z[k] = sp[k].z; rs[k] = sp[k].rs;
+            ok = ok && ints_exact<T>(sp[k].z, qmax);
+#pragma unroll
+            for (int e = (UNIFORM ? 0 : k); e < (UNIFORM ? VEC : k + 1); ++e) {
+                v0.e[e] = from_f<T>(sp[k].mn); v1.e[e] = from_f<T>(sp[k].mx); v2.e[e] = from_f<T>(sp[k].s);
+                v3.e[e] = from_f<T>(sp[k].zp); v4.e[e] = from_f<T>(sp[k].z);
+            }
+        }
+        if (blockIdx.y == 0 && w == 0) {
+            st_pack<T, VEC>(vec + col0, v0); st_pack<T, VEC>(vec + C + col0, v1); st_pack<T, VEC>(vec + 2ll * C + col0, v2);
+            st_pack<T, VEC>(vec + 3ll * C + col0, v3); st_pack<T, VEC>(vec + 4ll * C + col0, v4);
+        }
+    }
+    const bool exact_int = __all(ok);
+    auto stream_rows = [&](auto exact_tag) {
+        constexpr bool EX = decltype(exact_tag)::value;
+        auto body = [&](const Pack<T, VEC>& v, long long rr) {
+            Pack<T, VEC> o;
+            Pack<uint8_t, VEC> cd;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int k = UNIFORM ? 0 : e;
+                const float xi = col_level<T>(to_f<T>(v.e[e]), s[k], rs[k], z[k], EX);
+                const float xc = clampf(xi, 0.f, qmax);
+                o.e[e] = from_f<T>(affine_dequant<T>(xc, s[k], z[k], EX));
+                if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
+            }
+            st_pack<T, VEC>(out + rr * C + col0, o);
+            if (codes) st_pack<uint8_t, VEC>(codes + rr * C + col0, cd);
+        };
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if (r + 4 * u < r1) body(first[u], r + 4 * u);
+        r += 4 * DEPTH;
+        for (; r + (DEPTH - 1) * 4 < r1; r += DEPTH * 4) {
+            Pack<T, VEC> a[DEPTH];
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) a[u] = ld_pack<T, VEC>(x + (r + 4 * u) * C + col0);
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) body(a[u], r + 4 * u);
+        }
+        for (; r < r1; r += 4) body(ld_pack<T, VEC>(x + r * C + col0), r);
+    };
+    if (sizeof(T) == 4 || exact_int) stream_rows(std::true_type{});
+    else stream_rows(std::false_type{});
+}
+
+// ---------------------------------------------------------------------------------------------
 // channel gather out[r, c] = x[r, idx[c]]: rows are staged in LDS with coalesced 16-byte loads and
 // read back through the index, stores are coalesced again.
 // ---------------------------------------------------------------------------------------------
@@ -462,6 +744,96 @@ extern "C" int miq_act_calib_quant_fwd(const void* x, const void* cached_min, co
                            cmin_out, cmax_out, scale_out, zp_out, rzp_out, dtype, stream);
     if (rc) return rc;
     return miq_colquant_fwd(x, scale_out, rzp_out, out, codes_out, R, C, n_bits, dtype, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fresh statistics: statistics kernel + quantize kernel over up to kMaxSlabs slabs of one shape
+// ---------------------------------------------------------------------------------------------
+constexpr int kSlotReplicas = 8;  // replicas the workspace is sized for
+
+static inline int64_t fresh_slots(int64_t C, int n_clusters, int64_t covered) { return (int64_t)n_clusters + (C - covered); }
+static inline int64_t fresh_table_words(int64_t nslot) { return (int64_t)kSlotStride * nslot * kSlotReplicas; }
+
+extern "C" int64_t miq_act_fresh_workspace(int n, int64_t C, int n_clusters, int64_t covered) {
+    if (n <= 0 || C <= 0 || n_clusters < 0 || covered < 0 || covered > C) return 0;
+    return (kSlotStride + (int64_t)n * fresh_table_words(fresh_slots(C, n_clusters, covered))) * (int64_t)sizeof(u64);
+}
+
+template <typename T, int VEC, int NREP>
+static void launch_fresh_quant(bool uniform, dim3 grid, hipStream_t stream, const SlabPtrs& xs, const SlotMap& sm, u64* ws,
+                               long long ws_stride, const SlabOuts& outs, const SlabOuts& codes, const SlabOuts& vecs, long long R,
+                               int C, int rpc, float qmax) {
+    if (uniform)
+        hipLaunchKernelGGL((k_colquant_slots<T, VEC, 4, NREP, true>), grid, dim3(256), 0, stream, xs, sm, ws, ws_stride, outs, codes,
+                           vecs, R, C, rpc, qmax);
+    else
+        hipLaunchKernelGGL((k_colquant_slots<T, VEC, 4, NREP, false>), grid, dim3(256), 0, stream, xs, sm, ws, ws_stride, outs, codes,
+                           vecs, R, C, rpc, qmax);
+}
+
+template <typename T>
+static int act_fresh_t(int n, const void* const* x, int64_t cluster_size, const int* slot_of, int n_clusters, int64_t covered,
+                       int n_bits, void* workspace, void* const* out, void* const* codes_out, void* const* stats_out, long long R,
+                       long long C, hipStream_t stream) {
+    constexpr int N = VecOf<T>::N;
+    SlabPtrs xs{};
+    SlabOuts outs{}, codes{}, vecs{};
+    bool vec_ok = (C % N == 0);
+    for (int i = 0; i < n; ++i) {
+        MIQ_CHECK_ARG(x[i] && out[i] && stats_out[i], "miq_act_fresh_quant_fwd: null pointer in slab %d", i);
+        xs.p[i] = x[i];
+        outs.p[i] = out[i];
+        vecs.p[i] = stats_out[i];
+        codes.p[i] = codes_out ? codes_out[i] : nullptr;
+        vec_ok = vec_ok && aligned16(x[i]) && aligned16(out[i]) && aligned16(stats_out[i]) &&
+                 (!codes.p[i] || (reinterpret_cast<uintptr_t>(codes.p[i]) % N) == 0);
+    }
+    const int vec = vec_ok ? N : 1;
+    const int tiles = (int)((C / vec + 63) / 64);
+    const int nchunk = pick_chunks(R, tiles);
+    const int rpc = (int)((R + nchunk - 1) / nchunk);
+    const int64_t nslot = fresh_slots(C, n_clusters, covered);
+    const long long ws_stride = fresh_table_words(nslot);
+    // every row chunk feeds every slot its column tile touches: spread them over replicas when there are many
+    const int nrep = nchunk > 16 ? kSlotReplicas : 1;
+    const SlotMap sm{cluster_size > 0 ? nullptr : slot_of, (int)cluster_size, (int)covered, n_clusters};
+    const bool uniform = vec == 1 || (cluster_size > 0 && cluster_size % vec == 0 && covered == C);
+    const float qmax = (float)((1 << n_bits) - 1);
+    const dim3 grid(tiles, nchunk, n);
+    u64* ws = static_cast<u64*>(workspace);
+    if (vec_ok) {
+        hipLaunchKernelGGL((k_colstat_slots<T, N, 4>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
+        if (nrep == 1) launch_fresh_quant<T, N, 1>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
+        else launch_fresh_quant<T, N, kSlotReplicas>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
+    } else {
+        hipLaunchKernelGGL((k_colstat_slots<T, 1, 4>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
+        if (nrep == 1) launch_fresh_quant<T, 1, 1>(true, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
+        else launch_fresh_quant<T, 1, kSlotReplicas>(true, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
+    }
+    MIQ_CHECK_LAUNCH("miq_act_fresh_quant_fwd");
+    return 0;
+}
+
+extern "C" int miq_act_fresh_quant_fwd(int n, const void* const* x, int64_t cluster_size, const int* slot_of, int n_clusters,
+                                       int64_t covered, int n_bits, void* workspace, void* const* out, void* const* codes_out,
+                                       void* const* stats_out, int64_t R, int64_t C, int dtype, void* stream) {
+    if (n == 0 || R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(n > 0 && n <= kMaxSlabs, "miq_act_fresh_quant_fwd: %d slabs (1..%d per call)", n, kMaxSlabs);
+    MIQ_CHECK_ARG(x && out && stats_out && workspace && R > 0 && C > 0 && C < (1ll << 31),
+                  "miq_act_fresh_quant_fwd: null pointer or bad shape (R=%lld C=%lld)", (long long)R, (long long)C);
+    MIQ_CHECK_ARG(n_clusters >= 0 && covered >= 0 && covered <= C && (cluster_size > 0 || slot_of || n_clusters == 0),
+                  "miq_act_fresh_quant_fwd: unequal clusters need the channel -> slot map");
+    MIQ_CHECK_ARG(cluster_size <= 0 || cluster_size * n_clusters == covered, "miq_act_fresh_quant_fwd: cluster_size * n_clusters != covered");
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && (!codes_out || n_bits <= 8), "miq_act_fresh_quant_fwd: n_bits=%d unsupported", n_bits);
+    MIQ_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 127u) == 0, "miq_act_fresh_quant_fwd: workspace must be 128-byte aligned");
+    if (dtype == MIQ_F32)
+        return act_fresh_t<float>(n, x, cluster_size, slot_of, n_clusters, covered, n_bits, workspace, out, codes_out, stats_out, R, C,
+                                  (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return act_fresh_t<__half>(n, x, cluster_size, slot_of, n_clusters, covered, n_bits, workspace, out, codes_out, stats_out, R, C,
+                                   (hipStream_t)stream);
+    miq_set_error("miq_act_fresh_quant_fwd: unsupported dtype %d", dtype);
+    return -22;
 }
 
 // ---------------------------------------------------------------------------------------------

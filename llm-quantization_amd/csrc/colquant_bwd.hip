@@ -45,6 +45,30 @@ template <> __device__ __forceinline__ __half direct_out<__half>(__half graw, fl
     return m ? graw : off;
 }
 
+// One activation slab of a backward launch (blockIdx.z selects it; the weight-side entry points pass one).
+// The extremes an element is compared with are the per-channel statistics (chan_min / chan_max, fp32) when the forward
+// kept them, else the merged statistics kmin / kmax themselves: an element equals its cluster's maximum exactly when it
+// equals its channel's maximum and that channel attains the cluster maximum, so both forms select the same elements.
+struct BwdSlab {
+    const void* x;
+    const void* g;
+    const void* scale;
+    const void* rzp;
+    const void* kmin;        // [C] merged statistics in the tensor dtype
+    const void* kmax;
+    const float* chan_min;   // [C] or nullptr
+    const float* chan_max;
+    void* dx;
+    float* ws;               // part [3, nchunk, C] | sums [3, C] | share_min [C] | share_max [C] | flag
+};
+constexpr int kMaxBwdSlabs = 8;
+struct BwdSlabs { BwdSlab s[kMaxBwdSlabs]; };
+
+template <typename T>
+__device__ __forceinline__ float extreme_at(const float* chan, const void* merged, long long c) {
+    return chan ? chan[c] : to_f<T>(static_cast<const T*>(merged)[c]);
+}
+
 // dx = direct path; partial sums per (row chunk, channel): [0] dS, [1] #x==chan_max, [2] #x==chan_min.
 // The per-element arithmetic is what bounds this kernel for fp16 (6 bytes per element), so it is kept short:
 // tie counts are integer adds of the compare result, the clamp is a median-of-three (a NaN level, which
@@ -52,16 +76,23 @@ template <> __device__ __forceinline__ __half direct_out<__half>(__half graw, fl
 // re-roundings of integer intermediates are skipped when every level is exactly representable.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256, 4)  // four waves per SIMD: all four blocks of a CU resident
-k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ scale,
-                const T* __restrict__ rzp, const float* __restrict__ chan_min, const float* __restrict__ chan_max,
-                float* __restrict__ part, T* __restrict__ dx, long long R, int C, int rows_per_chunk, float qmax) {
+k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qmax, int flagged) {
     __shared__ float sm[3][4][64 * VEC];
+    const BwdSlab& sb = slabs.s[blockIdx.z];
+    const T* __restrict__ x = static_cast<const T*>(sb.x);
+    const T* __restrict__ g = static_cast<const T*>(sb.g);
+    const T* __restrict__ scale = static_cast<const T*>(sb.scale);
+    const T* __restrict__ rzp = static_cast<const T*>(sb.rzp);
+    float* __restrict__ part = sb.ws;
+    T* __restrict__ dx = static_cast<T*>(sb.dx);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
     const bool valid = col0 < C;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
+    if (flagged && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        sb.ws[(3ll * gridDim.y + 5) * C] = 0.f;  // "some cluster left its shares to the correction kernel": set by k_colbwd_cluster
     float acc[VEC];
     int nmx[VEC], nmn[VEC];
     float s[VEC], rs[VEC], z[VEC], cmn[VEC], cmx[VEC];
@@ -95,8 +126,8 @@ k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __res
             s[e] = to_f<T>(ps.e[e]);
             rs[e] = 1.0f / s[e];
             z[e] = to_f<T>(pz.e[e]);
-            cmn[e] = chan_min[col0 + e];
-            cmx[e] = chan_max[col0 + e];
+            cmn[e] = extreme_at<T>(sb.chan_min, sb.kmin, col0 + e);
+            cmx[e] = extreme_at<T>(sb.chan_max, sb.kmax, col0 + e);
             ok = ok && ints_exact<T>(z[e], qmax);
         }
     }
@@ -169,8 +200,10 @@ k_colbwd_stream(const T* __restrict__ x, const T* __restrict__ g, const T* __res
 // fold the row-chunk partials into sums[3, C] (the per-chunk counts stay: the correction kernel reads
 // them).  Block = 64 channels x 4 waves, wave w sums chunks w, w+4, ...
 __global__ void __launch_bounds__(256)
-k_colbwd_fold(const float* __restrict__ part, float* __restrict__ sums, int nchunk, int C) {
+k_colbwd_fold(BwdSlabs slabs, int nchunk, int C) {
     __shared__ float sm[4][64];
+    const float* __restrict__ part = slabs.s[blockIdx.z].ws;
+    float* __restrict__ sums = slabs.s[blockIdx.z].ws + 3ll * nchunk * C;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int k = blockIdx.y;  // plane: dS, #max, #min
@@ -202,11 +235,20 @@ k_colbwd_fold(const float* __restrict__ part, float* __restrict__ sums, int nchu
 // statistics) is spread over up to 16 blocks instead of one block walking all channels.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__ chan_min,
-                const float* __restrict__ chan_max, const T* __restrict__ kmin, const T* __restrict__ kmax,
-                const int* __restrict__ starts, int ncl, float qmax, float* __restrict__ share_min,
-                float* __restrict__ share_max) {
+k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ starts, int ncl, float qmax) {
     __shared__ float lds[48];
+    const BwdSlab& sb = slabs.s[blockIdx.z];
+    const float* __restrict__ sums = sb.ws + 3ll * nchunk * C;
+    float* __restrict__ share_min = sb.ws + (3ll * nchunk + 3) * C;
+    float* __restrict__ share_max = share_min + C;
+    const T* __restrict__ kmin = static_cast<const T*>(sb.kmin);
+    const T* __restrict__ kmax = static_cast<const T*>(sb.kmax);
+    const float* __restrict__ chan_min = sb.chan_min;
+    const float* __restrict__ chan_max = sb.chan_max;
+    // does channel c attain the cluster extreme?  With per-channel statistics: its own extreme equals the merged one;
+    // without: it holds at least one element equal to the merged extreme
+    auto at_max = [&](int c, float mx) { return chan_max ? chan_max[c] == mx : sums[(long long)C + c] > 0.f; };
+    auto at_min = [&](int c, float mn) { return chan_min ? chan_min[c] == mn : sums[2ll * C + c] > 0.f; };
     const int k = blockIdx.x;
     const bool own = k >= ncl;
     const int st = own ? starts[ncl] : starts[k];
@@ -230,31 +272,32 @@ k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__
     // this block's first channel: loaded before the reduction so that its shares need no dependent loads afterwards
     // (clusters of up to 256 channels per slice are written from registers)
     const bool has0 = first < en;
-    float n1 = 1.f, n2 = 1.f, cx0 = 0.f, cn0 = 0.f;
+    float n1 = 1.f, n2 = 1.f;
+    bool ax0 = false, an0 = false;
     if (has0) {
         n1 = colsum(1, first);
         n2 = colsum(2, first);
-        cx0 = chan_max[first];
-        cn0 = chan_min[first];
+        ax0 = at_max(first, mx);
+        an0 = at_min(first, mn);
     }
     // cluster totals: dS, number of channels attaining the cluster max / min
     float acc[3] = {0.f, 0.f, 0.f};
     for (int c = st + threadIdx.x; c < en; c += 1024) {
-        float ds[4], cx[4], cn[4];
+        float ds[4];
+        bool ax[4], an[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cc = c + 256 * u;
             const bool in = cc < en;
             ds[u] = in ? colsum(0, cc) : 0.f;
-            cx[u] = in ? chan_max[cc] : 0.f;
-            cn[u] = in ? chan_min[cc] : 0.f;
+            ax[u] = in && at_max(cc, mx);
+            an[u] = in && at_min(cc, mn);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool in = c + 256 * u < en;
             acc[0] += ds[u];
-            acc[1] += (in && cx[u] == mx) ? 1.f : 0.f;
-            acc[2] += (in && cn[u] == mn) ? 1.f : 0.f;
+            acc[1] += ax[u] ? 1.f : 0.f;
+            acc[2] += an[u] ? 1.f : 0.f;
         }
     }
     team_sum<256, 3>(acc, lds);
@@ -262,12 +305,140 @@ k_colbwd_shares(const float* __restrict__ sums, int C, const float* __restrict__
     const bool live = s_raw >= lo && s_raw <= kClipHi;
     const float d = live ? acc[0] / qmax : 0.f;
     if (has0) {
-        share_max[first] = (cx0 == mx) ? (d / acc[1]) / n1 : 0.f;
-        share_min[first] = (cn0 == mn) ? (-d / acc[2]) / n2 : 0.f;
+        share_max[first] = ax0 ? (d / acc[1]) / n1 : 0.f;
+        share_min[first] = an0 ? (-d / acc[2]) / n2 : 0.f;
     }
     for (int c = first + step; c < en; c += step) {
-        share_max[c] = (chan_max[c] == mx) ? (d / acc[1]) / colsum(1, c) : 0.f;
-        share_min[c] = (chan_min[c] == mn) ? (-d / acc[2]) / colsum(2, c) : 0.f;
+        share_max[c] = at_max(c, mx) ? (d / acc[1]) / colsum(1, c) : 0.f;
+        share_min[c] = at_min(c, mn) ? (-d / acc[2]) / colsum(2, c) : 0.f;
+    }
+}
+
+// Fold + shares + sparse correction in one launch, for clusters of at most kClusterMax channels: one block per
+// cluster.  The arithmetic is that of k_colbwd_fold followed by k_colbwd_shares, in the same order (per channel: four
+// interleaved chunk sequences summed 16 at a time, then (s0 + s1) + (s2 + s3); per cluster: the strided sum and tree of
+// k_colbwd_shares), so the shares carry the same bits.  While folding the tie counts the block notes which (row chunk,
+// channel) pairs hold an element at a cluster extreme; up to kPairMax of them are corrected right here (one wave scans
+// the pair's rows), and the shares it publishes for k_colbwd_fixup are then zero.  A cluster with more pairs (ReLU-style
+// mass ties) publishes its shares and raises the slab's flag, and k_colbwd_fixup streams over it.
+constexpr int kClusterMax = 1024;
+constexpr int kPairMax = 64;
+template <typename T>
+__global__ void __launch_bounds__(1024)
+k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, const int* __restrict__ starts, float qmax) {
+    __shared__ float part_l[3][4][256];
+    __shared__ float tot[3][kClusterMax];
+    __shared__ float shr[2][kClusterMax];
+    __shared__ float lds[48];
+    __shared__ int pairs[kPairMax];
+    __shared__ int npairs;
+    const BwdSlab& sb = slabs.s[blockIdx.z];
+    const float* __restrict__ part = sb.ws;
+    float* __restrict__ share_min = sb.ws + (3ll * nchunk + 3) * C;
+    float* __restrict__ share_max = share_min + C;
+    const int st = starts[blockIdx.x], en = starts[blockIdx.x + 1];
+    const int W = en - st;
+    if (W <= 0) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) npairs = 0;
+    __syncthreads();
+    // per-channel fold, 256 channels at a time: thread (w, c) sums chunks w, w + 4, ... of channel c
+    for (int c0 = 0; c0 < W; c0 += 256) {
+        const int c = tid & 255, w = tid >> 8;
+        const bool valid = c0 + c < W;
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            const float* p = part + st + c0 + c;
+            for (int j0 = w; j0 < nchunk; j0 += 64) {
+                float v[3][16];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int j = j0 + 4 * u;
+                        v[k][u] = j < nchunk ? p[((long long)k * nchunk + j) * C] : 0.f;
+                    }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    acc[k] += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7])) +
+                              (((v[k][8] + v[k][9]) + (v[k][10] + v[k][11])) + ((v[k][12] + v[k][13]) + (v[k][14] + v[k][15])));
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int bits = (v[1][u] > 0.f ? 1 : 0) | (v[2][u] > 0.f ? 2 : 0);
+                    if (bits) {
+                        const int i = atomicAdd(&npairs, 1);
+                        if (i < kPairMax) pairs[i] = ((j0 + 4 * u) << 12) | ((c0 + c) << 2) | bits;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) part_l[k][w][c] = acc[k];
+        __syncthreads();
+        if (w == 0 && valid) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tot[k][c0 + c] = (part_l[k][0][c] + part_l[k][1][c]) + (part_l[k][2][c] + part_l[k][3][c]);
+        }
+        __syncthreads();
+    }
+    // cluster totals in the order of k_colbwd_shares: 256 strided partial sums, then the tree of team_sum<256, 3>
+    const float mn = to_f<T>(static_cast<const T*>(sb.kmin)[st]), mx = to_f<T>(static_cast<const T*>(sb.kmax)[st]);
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (tid < 256) {
+        for (int c = tid; c < W; c += 1024) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = c + 256 * u;
+                const bool in = cc < W;
+                acc[0] += in ? tot[0][cc] : 0.f;
+                acc[1] += (in && tot[1][cc] > 0.f) ? 1.f : 0.f;
+                acc[2] += (in && tot[2][cc] > 0.f) ? 1.f : 0.f;
+            }
+        }
+    }
+    team_sum<256, 3>(acc, lds);  // every wave takes part in the barriers; the sums are those of waves 0..3
+    const float lo = rnd<T>(kClipLo);
+    const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
+    const bool live = s_raw >= lo && s_raw <= kClipHi;
+    const float d = live ? acc[0] / qmax : 0.f;
+    const bool mass = npairs > kPairMax;
+    for (int c = tid; c < W; c += 1024) {
+        const float hx = tot[1][c] > 0.f ? (d / acc[1]) / tot[1][c] : 0.f;
+        const float hn = tot[2][c] > 0.f ? (-d / acc[2]) / tot[2][c] : 0.f;
+        shr[0][c] = hx;
+        shr[1][c] = hn;
+        share_max[st + c] = mass ? hx : 0.f;
+        share_min[st + c] = mass ? hn : 0.f;
+    }
+    if (mass) {
+        if (tid == 0) sb.ws[(3ll * nchunk + 5) * C] = 1.f;
+        return;
+    }
+    __syncthreads();
+    // sparse correction: wave v takes pairs v, v + 16, ...; its lanes scan the rows of the pair's chunk
+    const T* __restrict__ x = static_cast<const T*>(sb.x);
+    T* __restrict__ dx = static_cast<T*>(sb.dx);
+    const int lane = tid & 63;
+    for (int i = tid >> 6; i < npairs; i += 16) {
+        const int e = pairs[i];
+        const int j = e >> 12, c = (e >> 2) & 1023;
+        const float hx = shr[0][c], hn = shr[1][c];
+        const bool amx = (e & 1) && hx != 0.f, amn = (e & 2) && hn != 0.f;  // a NaN share is added like any other value
+        if (!amx && !amn) continue;
+        const long long r0 = (long long)j * rows_per_chunk;
+        long long r1 = r0 + rows_per_chunk;
+        if (r1 > R) r1 = R;
+        for (long long r = r0 + lane; r < r1; r += 64) {
+            const long long at = r * C + st + c;
+            const float xv = to_f<T>(x[at]);
+            const bool hit_x = amx && xv == mx, hit_n = amn && xv == mn;
+            if (hit_x || hit_n) {
+                float v = to_f<T>(dx[at]);
+                if (hit_x) v += hx;
+                if (hit_n) v += hn;
+                dx[at] = from_f<T>(v);
+            }
+        }
     }
 }
 
@@ -345,10 +516,15 @@ __device__ __forceinline__ void ld_floats(const float* __restrict__ p, float* ou
 // mass ties every block streams its tile with coalesced 16-byte accesses.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-k_colbwd_fixup(const T* __restrict__ x, const float* __restrict__ part, int nchunk,
-               const float* __restrict__ chan_min, const float* __restrict__ chan_max,
-               const float* __restrict__ share_min, const float* __restrict__ share_max, T* __restrict__ dx,
-               long long R, int C, int rows_per_chunk) {
+k_colbwd_fixup(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, int flagged) {
+    const BwdSlab& sb = slabs.s[blockIdx.z];
+    // behind k_colbwd_cluster: nothing to do unless a cluster with mass ties left its shares here
+    if (flagged && sb.ws[(3ll * nchunk + 5) * C] == 0.f) return;
+    const T* __restrict__ x = static_cast<const T*>(sb.x);
+    const float* __restrict__ part = sb.ws;
+    const float* __restrict__ share_min = sb.ws + (3ll * nchunk + 3) * C;
+    const float* __restrict__ share_max = share_min + C;
+    T* __restrict__ dx = static_cast<T*>(sb.dx);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
     if (col0 >= C) return;
@@ -360,8 +536,16 @@ k_colbwd_fixup(const T* __restrict__ x, const float* __restrict__ part, int nchu
     ld_floats<VEC>(part + ((long long)2 * nchunk + blockIdx.y) * C + col0, nmn);
     ld_floats<VEC>(share_max + col0, hmx);
     ld_floats<VEC>(share_min + col0, hmn);
-    ld_floats<VEC>(chan_max + col0, cmx);
-    ld_floats<VEC>(chan_min + col0, cmn);
+    if (sb.chan_max) {
+        ld_floats<VEC>(sb.chan_max + col0, cmx);
+        ld_floats<VEC>(sb.chan_min + col0, cmn);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            cmx[e] = to_f<T>(static_cast<const T*>(sb.kmax)[col0 + e]);
+            cmn[e] = to_f<T>(static_cast<const T*>(sb.kmin)[col0 + e]);
+        }
+    }
     bool amx[VEC], amn[VEC], any = false;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -403,53 +587,53 @@ k_colbwd_fixup(const T* __restrict__ x, const float* __restrict__ part, int nchu
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Launches the backward over `n` slabs of one shape.  merged: fold + shares + sparse correction in k_colbwd_cluster
+// (needs clusters of at most kClusterMax channels that cover every channel, and the flag word behind the workspace).
 template <typename T>
-static int colquant_bwd_t(const void* g, const void* x, const void* scale, const void* rzp, const float* chan_min,
-                          const float* chan_max, const void* kmin, const void* kmax, const int* starts, int ncl,
-                          long long covered, float* ws, int nchunk, void* dx, long long R, long long C, int n_bits,
-                          int phase, hipStream_t stream) {
+static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const int* starts, int ncl, long long covered,
+                               int nchunk, long long R, long long C, int n_bits, int phase, bool merged, hipStream_t stream,
+                               const char* who) {
     constexpr int N = VecOf<T>::N;
-    const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(scale) && aligned16(rzp) &&
-                        aligned16(ws) && aligned16(chan_min) && aligned16(chan_max);
+    bool vec_ok = (C % N == 0);
+    for (int i = 0; i < n; ++i) {
+        const BwdSlab& b = slabs.s[i];
+        vec_ok = vec_ok && aligned16(b.x) && aligned16(b.g) && aligned16(b.dx) && aligned16(b.scale) && aligned16(b.rzp) &&
+                 aligned16(b.ws) && aligned16(b.chan_min) && aligned16(b.chan_max);
+    }
     const float qmax = (float)((1 << n_bits) - 1);
     const int tiles = (int)(vec_ok ? (C / N + 63) / 64 : (C + 63) / 64);
     const int rpc = (int)((R + nchunk - 1) / nchunk);
-    const dim3 grid(tiles, nchunk), block(256);
-    if (!chan_min) {  // eval mode
+    const dim3 grid(tiles, nchunk, n), block(256);
+    if (!routed) {  // eval mode: one slab
+        const BwdSlab& b = slabs.s[0];
         if (vec_ok)
-            hipLaunchKernelGGL((k_colbwd_apply<T, N>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
-                               (const T*)rzp, (T*)dx, R, (int)C, rpc, qmax);
+            hipLaunchKernelGGL((k_colbwd_apply<T, N>), dim3(tiles, nchunk), block, 0, stream, (const T*)b.x, (const T*)b.g,
+                               (const T*)b.scale, (const T*)b.rzp, (T*)b.dx, R, (int)C, rpc, qmax);
         else
-            hipLaunchKernelGGL((k_colbwd_apply<T, 1>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
-                               (const T*)rzp, (T*)dx, R, (int)C, rpc, qmax);
-        MIQ_CHECK_LAUNCH("miq_colquant_bwd");
+            hipLaunchKernelGGL((k_colbwd_apply<T, 1>), dim3(tiles, nchunk), block, 0, stream, (const T*)b.x, (const T*)b.g,
+                               (const T*)b.scale, (const T*)b.rzp, (T*)b.dx, R, (int)C, rpc, qmax);
+        MIQ_CHECK_LAUNCH(who);
         return 0;
     }
-    float* part = ws;                          // [3, nchunk, C]
-    float* sums = ws + 3ll * nchunk * C;       // [3, C]
-    float* share_min = sums + 3ll * C;         // [C]
-    float* share_max = share_min + C;          // [C]
+    const int flagged = merged ? 1 : 0;
     if (phase != 2) {
-        if (vec_ok)
-            hipLaunchKernelGGL((k_colbwd_stream<T, N>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
-                               (const T*)rzp, chan_min, chan_max, part, (T*)dx, R, (int)C, rpc, qmax);
-        else
-            hipLaunchKernelGGL((k_colbwd_stream<T, 1>), grid, block, 0, stream, (const T*)x, (const T*)g, (const T*)scale,
-                               (const T*)rzp, chan_min, chan_max, part, (T*)dx, R, (int)C, rpc, qmax);
-        hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64), 3), block, 0, stream, part, sums, nchunk, (int)C);
+        if (vec_ok) hipLaunchKernelGGL((k_colbwd_stream<T, N>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
+        else hipLaunchKernelGGL((k_colbwd_stream<T, 1>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
+        if (!merged)
+            hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64), 3, n), block, 0, stream, slabs, nchunk, (int)C);
     }
     if (phase != 1) {
-        const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
-        hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk, cluster_slices(C, nblk)), block, 0, stream, sums, (int)C, chan_min, chan_max,
-                           (const T*)kmin, (const T*)kmax, starts, ncl, qmax, share_min, share_max);
-        if (vec_ok)
-            hipLaunchKernelGGL((k_colbwd_fixup<T, N>), grid, block, 0, stream, (const T*)x, part, nchunk, chan_min, chan_max,
-                               share_min, share_max, (T*)dx, R, (int)C, rpc);
-        else
-            hipLaunchKernelGGL((k_colbwd_fixup<T, 1>), grid, block, 0, stream, (const T*)x, part, nchunk, chan_min, chan_max,
-                               share_min, share_max, (T*)dx, R, (int)C, rpc);
+        if (merged) {
+            hipLaunchKernelGGL((k_colbwd_cluster<T>), dim3(ncl, 1, n), dim3(1024), 0, stream, slabs, nchunk, R, (int)C, rpc, starts, qmax);
+        } else {
+            const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
+            hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk, cluster_slices(C, nblk), n), block, 0, stream, slabs, nchunk, (int)C,
+                               starts, ncl, qmax);
+        }
+        if (vec_ok) hipLaunchKernelGGL((k_colbwd_fixup<T, N>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);
+        else hipLaunchKernelGGL((k_colbwd_fixup<T, 1>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);
     }
-    MIQ_CHECK_LAUNCH("miq_colquant_bwd");
+    MIQ_CHECK_LAUNCH(who);
     return 0;
 }
 
@@ -469,12 +653,58 @@ extern "C" int miq_colquant_bwd(const void* grad_out, const void* x, const void*
     MIQ_CHECK_ARG((chan_min == nullptr) == (chan_max == nullptr), "miq_colquant_bwd: chan_min/chan_max must come together");
     MIQ_CHECK_ARG(!chan_min || (kmin && kmax && starts && workspace && covered >= 0 && covered <= C),
                   "miq_colquant_bwd: routing needs kmin, kmax, starts and a workspace");
+    BwdSlabs slabs{};
+    slabs.s[0] = BwdSlab{x, grad_out, scale, rzp, kmin, kmax, chan_min, chan_max, dx, workspace};
     if (dtype == MIQ_F32)
-        return colquant_bwd_t<float>(grad_out, x, scale, rzp, chan_min, chan_max, kmin, kmax, starts, n_clusters, covered,
-                                     workspace, nchunk, dx, R, C, n_bits, phase, (hipStream_t)stream);
+        return colquant_bwd_launch<float>(slabs, 1, chan_min != nullptr, starts, n_clusters, covered, nchunk, R, C, n_bits, phase,
+                                          false, (hipStream_t)stream, "miq_colquant_bwd");
     if (dtype == MIQ_F16)
-        return colquant_bwd_t<__half>(grad_out, x, scale, rzp, chan_min, chan_max, kmin, kmax, starts, n_clusters, covered,
-                                      workspace, nchunk, dx, R, C, n_bits, phase, (hipStream_t)stream);
+        return colquant_bwd_launch<__half>(slabs, 1, chan_min != nullptr, starts, n_clusters, covered, nchunk, R, C, n_bits, phase,
+                                           false, (hipStream_t)stream, "miq_colquant_bwd");
     miq_set_error("miq_colquant_bwd: unsupported dtype %d", dtype);
     return -22;
+}
+
+// floats of workspace per slab of the fresh-statistics backward: the partial planes, the folded sums, the shares and
+// the flag word, padded to a multiple of four floats
+static inline int64_t fresh_bwd_ws_floats(int64_t R, int64_t C, int dtype) {
+    const int64_t nchunk = miq_colstat_chunks(R, C, dtype);
+    return ((3 * nchunk + 5) * C + 4 + 3) / 4 * 4;
+}
+
+extern "C" int64_t miq_act_fresh_bwd_workspace(int n, int64_t R, int64_t C, int dtype) {
+    if (n <= 0 || R <= 0 || C <= 0) return 0;
+    return (int64_t)n * fresh_bwd_ws_floats(R, C, dtype) * (int64_t)sizeof(float);
+}
+
+extern "C" int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const void* const* x, const void* const* stats,
+                                       int64_t cluster_size, const int* starts, int n_clusters, int64_t covered, int n_bits,
+                                       void* workspace, void* const* dx, int64_t R, int64_t C, int dtype, void* stream) {
+    if (n == 0 || R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(n > 0 && n <= kMaxBwdSlabs, "miq_act_fresh_quant_bwd: %d slabs (1..%d per call)", n, kMaxBwdSlabs);
+    MIQ_CHECK_ARG(grad_out && x && stats && dx && starts && workspace && R > 0 && C > 0 && C < (1ll << 31),
+                  "miq_act_fresh_quant_bwd: null pointer or bad shape");
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && n_clusters >= 0 && covered >= 0 && covered <= C, "miq_act_fresh_quant_bwd: bad n_bits / cluster layout");
+    MIQ_CHECK_ARG(cluster_size <= 0 || cluster_size * n_clusters == covered, "miq_act_fresh_quant_bwd: cluster_size * n_clusters != covered");
+    MIQ_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0, "miq_act_fresh_quant_bwd: workspace must be 16-byte aligned");
+    if (dtype != MIQ_F32 && dtype != MIQ_F16) {
+        miq_set_error("miq_act_fresh_quant_bwd: unsupported dtype %d", dtype);
+        return -22;
+    }
+    const size_t es = dtype == MIQ_F16 ? 2 : 4;
+    const int64_t stride = fresh_bwd_ws_floats(R, C, dtype);
+    BwdSlabs slabs{};
+    for (int i = 0; i < n; ++i) {
+        MIQ_CHECK_ARG(grad_out[i] && x[i] && stats[i] && dx[i], "miq_act_fresh_quant_bwd: null pointer in slab %d", i);
+        const char* v = static_cast<const char*>(stats[i]);  // [5, C]: merged min, merged max, scale, zero point, rounded zero point
+        slabs.s[i] = BwdSlab{x[i], grad_out[i], v + 2 * C * es, v + 4 * C * es, v, v + C * es, nullptr, nullptr, dx[i],
+                             static_cast<float*>(workspace) + i * stride};
+    }
+    const int nchunk = miq_colstat_chunks(R, C, dtype);
+    const bool merged = cluster_size > 0 && cluster_size <= kClusterMax && covered == C;
+    if (dtype == MIQ_F32)
+        return colquant_bwd_launch<float>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged,
+                                          (hipStream_t)stream, "miq_act_fresh_quant_bwd");
+    return colquant_bwd_launch<__half>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged,
+                                       (hipStream_t)stream, "miq_act_fresh_quant_bwd");
 }

@@ -37,6 +37,8 @@ def lib() -> ctypes.CDLL:
         _lib.miq_version.restype = ctypes.c_int
         _lib.miq_act_workspace.restype = ctypes.c_int64
         _lib.miq_act_static_capacity.restype = ctypes.c_int64
+        _lib.miq_act_fresh_workspace.restype = ctypes.c_int64
+        _lib.miq_act_fresh_bwd_workspace.restype = ctypes.c_int64
         _lib.miq_let_workspace.restype = ctypes.c_int64
         _lib.miq_rmsnorm_workspace.restype = ctypes.c_int64
         _lib.miq_col_sum_workspace.restype = ctypes.c_int64

@@ -214,6 +214,24 @@ class ClusterLayout:
         self.covered = starts[-1]
         self.C = C
         self.starts = torch.tensor(starts, dtype=torch.int32, device=device)
+        # equal-sized clusters (every layout the reorder stages produce) are addressed by arithmetic; anything else
+        # through a channel -> statistics-slot map (cluster id, or n_clusters + (c - covered) outside every cluster)
+        self.cluster_size = counts[0] if counts and counts[0] > 0 and all(c == counts[0] for c in counts) else 0
+        self._counts = counts
+        self._device = device
+        self._slot_of = None
+
+    @property
+    def slot_of(self):
+        if self.cluster_size:
+            return None
+        if self._slot_of is None:
+            slot = []
+            for k, n in enumerate(self._counts):
+                slot += [k] * n
+            slot += [self.n_clusters + i for i in range(self.C - self.covered)]
+            self._slot_of = torch.tensor(slot, dtype=torch.int32, device=self._device)
+        return self._slot_of
 
     @classmethod
     def get(cls, counts, C: int, device):
@@ -325,6 +343,67 @@ def act_calib_quant_fwd(x2d, n_bits: int, metric: str, layout: ClusterLayout, ca
     stats = {"cmin": outs[0], "cmax": outs[1], "scale": outs[2], "zp": outs[3], "rzp": outs[4],
              "chan_min": ws[0, rows - 1], "chan_max": ws[1, rows - 1]}
     return out, codes, stats
+
+
+_FRESH_WS = {}
+
+
+def _fresh_workspace(dev, nbytes: int):
+    """The statistics table of miq_act_fresh_quant_fwd: zero-filled once, then only ever handed to that function.
+    One per (device, stream): calls that share a table must be ordered on one stream."""
+    key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+    ws = _FRESH_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _FRESH_WS[key] = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def stats_of(vec):
+    """The [5, C] block of the fresh-statistics forward as the dictionary the quantizer modules publish."""
+    return {"cmin": vec[0], "cmax": vec[1], "scale": vec[2], "zp": vec[3], "rzp": vec[4], "vec": vec}
+
+
+def act_fresh_quant_fwd(xs, n_bits: int, layout: ClusterLayout, want_codes: bool = False):
+    """Calibrate (no cached statistics) + quantize up to 8 [R, C] slabs of one shape, dtype and cluster layout in
+    two launches (miq_act_fresh_quant_fwd).  Returns (outs, codes | None, vecs): vecs[i] is the [5, C] block
+    (merged min, merged max, scale, zero point, rounded zero point) of slab i."""
+    dev = L.check_gpu(*xs)
+    R, C = xs[0].shape
+    for x in xs:
+        if x.shape != xs[0].shape or x.dtype != xs[0].dtype:
+            raise L.MiqError("slabs of one call must share shape and dtype")
+    n = len(xs)
+    outs = [torch.empty_like(x) for x in xs]
+    codes = [torch.empty((R, C), dtype=torch.uint8, device=dev) for _ in xs] if want_codes else None
+    vecs = torch.empty((n, 5, C), dtype=xs[0].dtype, device=dev)
+    if R == 0 or C == 0:
+        return outs, codes, list(vecs)
+    nbytes = int(L.lib().miq_act_fresh_workspace(L.i32(n), L.i64(C), L.i32(layout.n_clusters), L.i64(layout.covered)))
+    with L.on_device(dev):
+        ws = _fresh_workspace(dev, nbytes)
+        L.call("miq_act_fresh_quant_fwd", L.i32(n), _ptr_table(xs), L.i64(layout.cluster_size), L.ptr(layout.slot_of),
+               L.i32(layout.n_clusters), L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(ws), _ptr_table(outs),
+               _ptr_table(codes) if want_codes else None, _ptr_table(list(vecs)), L.i64(R), L.i64(C),
+               L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+    return outs, codes, list(vecs)
+
+
+def act_fresh_quant_bwd(gs, xs, vecs, n_bits: int, layout: ClusterLayout):
+    """Backward of act_fresh_quant_fwd for the same slabs (miq_act_fresh_quant_bwd).  Returns the list of dx."""
+    dev = L.check_gpu(*gs, *xs, *vecs)
+    R, C = xs[0].shape
+    n = len(xs)
+    dxs = [torch.empty_like(x) for x in xs]
+    if R == 0 or C == 0:
+        return dxs
+    code = L.dtype_code(xs[0])
+    nbytes = int(L.lib().miq_act_fresh_bwd_workspace(L.i32(n), L.i64(R), L.i64(C), L.i32(code)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with L.on_device(dev):
+        L.call("miq_act_fresh_quant_bwd", L.i32(n), _ptr_table(gs), _ptr_table(xs), _ptr_table(vecs), L.i64(layout.cluster_size),
+               L.ptr(layout.starts), L.i32(layout.n_clusters), L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(ws),
+               _ptr_table(dxs), L.i64(R), L.i64(C), L.i32(code), L.stream_of(xs[0]))
+    return dxs
 
 
 def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
@@ -762,29 +841,70 @@ class ActCalibFQ(torch.autograd.Function):
                 cached_min = cached_min[:1].expand(C * k).contiguous()
                 cached_max = cached_max[:1].expand(C * k).contiguous()
         ctx.dp = dp
-        if synced:
-            st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max, dp=dp)
-            out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
-        else:
-            out, _, st = act_calib_quant_fwd(x2, n_bits, metric, layout, cached_min, cached_max)
         ctx.fresh = cached_min is None
         ctx.layout = layout
         ctx.n_bits = n_bits
-        ctx.save_for_backward(x2, st["scale"], st["rzp"], st["chan_min"], st["chan_max"], st["cmin"], st["cmax"])
+        ctx.vec_path = ctx.fresh and not synced and x2.numel() > 0
+        if ctx.vec_path:  # the training-step case: two launches, statistics merged by atomics
+            outs, _, vecs = act_fresh_quant_fwd([x2], n_bits, layout)
+            out, st = outs[0], stats_of(vecs[0])
+            ctx.save_for_backward(x2, vecs[0])
+        else:
+            if synced:
+                st = act_calibrate(x2, n_bits, metric, layout, cached_min, cached_max, dp=dp)
+                out, _ = colquant_fwd(x2, st["scale"], st["rzp"], n_bits)
+            else:
+                out, _, st = act_calib_quant_fwd(x2, n_bits, metric, layout, cached_min, cached_max)
+            ctx.save_for_backward(x2, st["scale"], st["rzp"], st["chan_min"], st["chan_max"], st["cmin"], st["cmax"])
         if k > 1:  # publish vectors of the caller's channel count
-            st = {n: (v if n.startswith("chan_") else v[:C]) for n, v in st.items()}
+            st = {n: (v if n.startswith("chan_") or n == "vec" else v[:C]) for n, v in st.items()}
         holder.update(st)
         return out.reshape(x.shape)
 
     @staticmethod
     def backward(ctx, g):
-        x2, s, z, chan_min, chan_max, kmin, kmax = ctx.saved_tensors
         if not ctx.fresh:
             raise L.MiqError("backward through cached activation statistics is not defined: call free() on the "
                              "quantizer after every optimizer step (the calibration loop does)")
+        if ctx.vec_path:
+            x2, vec = ctx.saved_tensors
+            dx = act_fresh_quant_bwd([g.contiguous().reshape(x2.shape)], [x2], [vec], ctx.n_bits, ctx.layout)[0]
+            return dx.reshape(g.shape), None, None, None, None, None, None, None
+        x2, s, z, chan_min, chan_max, kmin, kmax = ctx.saved_tensors
         dx = colquant_bwd(g.contiguous().reshape(x2.shape), x2, s, z, ctx.n_bits,
                           route=(chan_min, chan_max, kmin, kmax, ctx.layout), dp=ctx.dp)
         return dx.reshape(g.shape), None, None, None, None, None, None, None
+
+
+class ActCalibFQBatch(torch.autograd.Function):
+    """apply(n_bits, layout, holders, x_0, x_1, ...) -> (out_0, out_1, ...): several activations of one shape, dtype
+    and cluster layout (the q / k / v projection outputs of a block, say) calibrated with fresh statistics and
+    quantized by one pair of launches, and one backward; holders[i] receives the statistics of x_i."""
+
+    @staticmethod
+    def forward(ctx, n_bits, layout, holders, *xs):
+        C = xs[0].shape[-1]
+        x2s = [x.contiguous().reshape(-1, C) for x in xs]
+        outs, _, vecs = act_fresh_quant_fwd(x2s, n_bits, layout)
+        for h, v in zip(holders, vecs):
+            h.update(stats_of(v))
+        ctx.layout, ctx.n_bits, ctx.n = layout, n_bits, len(xs)
+        ctx.save_for_backward(*x2s, *vecs)
+        ctx.set_materialize_grads(False)
+        return tuple(o.reshape(x.shape) for o, x in zip(outs, xs))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        x2s, vecs = list(ctx.saved_tensors[:n]), list(ctx.saved_tensors[n:])
+        live = [i for i in range(n) if gs[i] is not None and ctx.needs_input_grad[3 + i]]
+        dxs = [None] * n
+        if live:
+            g2s = [gs[i].contiguous().reshape(x2s[i].shape) for i in live]
+            res = act_fresh_quant_bwd(g2s, [x2s[i] for i in live], [vecs[i] for i in live], ctx.n_bits, ctx.layout)
+            for i, d in zip(live, res):
+                dxs[i] = d.reshape(gs[i].shape)
+        return (None, None, None, *dxs)
 
 
 # ---------------------------------------------------------------------------------------------
