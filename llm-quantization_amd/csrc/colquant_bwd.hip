@@ -61,7 +61,7 @@ struct BwdSlab {
     void* dx;
     float* ws;               // part [3, nchunk, C] | sums [3, C] | share_min [C] | share_max [C] | flag
 };
-constexpr int kMaxBwdSlabs = 8;
+constexpr int kMaxBwdSlabs = 8;  // per launch (blockIdx.z)
 struct BwdSlabs { BwdSlab s[kMaxBwdSlabs]; };
 
 template <typename T>
@@ -74,9 +74,13 @@ __device__ __forceinline__ float extreme_at(const float* chan, const void* merge
 // tie counts are integer adds of the compare result, the clamp is a median-of-three (a NaN level, which
 // only +-inf inputs produce, is carried into the sum through the masked quotient instead), and the fp16
 // re-roundings of integer intermediates are skipped when every level is exactly representable.
-template <typename T, int VEC>
+// UNIFORM: the channels of a lane's pack share one cluster (equal clusters whose size is a multiple of VEC, merged
+// statistics): one scale / zero point / pair of extremes per lane instead of VEC of each, which is what lets the
+// vectorised kernels stay inside 128 registers without spilling.
+template <typename T, int VEC, bool UNIFORM>
 __global__ void __launch_bounds__(256, 4)  // four waves per SIMD: all four blocks of a CU resident
 k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qmax, int flagged) {
+    constexpr int NP = UNIFORM ? 1 : VEC;  // parameter sets per lane
     __shared__ float sm[3][4][64 * VEC];
     const BwdSlab& sb = slabs.s[blockIdx.z];
     const T* __restrict__ x = static_cast<const T*>(sb.x);
@@ -95,7 +99,7 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
         sb.ws[(3ll * gridDim.y + 5) * C] = 0.f;  // "some cluster left its shares to the correction kernel": set by k_colbwd_cluster
     float acc[VEC];
     int nmx[VEC], nmn[VEC];
-    float s[VEC], rs[VEC], z[VEC], cmn[VEC], cmx[VEC];
+    float s[NP], rs[NP], z[NP], cmn[NP], cmx[NP];
     bool ok = true;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -120,12 +124,11 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
     };
     if (valid) {
         load_batch(r0 + w);
-        Pack<T, VEC> ps = ld_pack<T, VEC>(scale + col0), pz = ld_pack<T, VEC>(rzp + col0);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            s[e] = to_f<T>(ps.e[e]);
+        for (int e = 0; e < NP; ++e) {
+            s[e] = to_f<T>(scale[col0 + e]);
             rs[e] = 1.0f / s[e];
-            z[e] = to_f<T>(pz.e[e]);
+            z[e] = to_f<T>(rzp[col0 + e]);
             cmn[e] = extreme_at<T>(sb.chan_min, sb.kmin, col0 + e);
             cmx[e] = extreme_at<T>(sb.chan_max, sb.kmax, col0 + e);
             ok = ok && ints_exact<T>(z[e], qmax);
@@ -136,7 +139,7 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
     // not the constant 0, and keeping it per channel in the common case costs registers this kernel lacks
     bool finite_scales = true;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) finite_scales = finite_scales && !(valid && s[e] != s[e]);
+    for (int e = 0; e < NP; ++e) finite_scales = finite_scales && !(valid && s[e] != s[e]);
     const bool no_nan = __all(finite_scales);
     auto stream_rows = [&](auto exact_tag, auto nan_tag) {
         constexpr bool EX = decltype(exact_tag)::value;
@@ -145,19 +148,20 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
             Pack<T, VEC> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
+                const int k = UNIFORM ? 0 : e;
                 const float xv = to_f<T>(pa.e[e]), gv = to_f<T>(pb.e[e]);
-                const float q = bwd_div<T>(xv, s[e], rs[e]);
+                const float q = bwd_div<T>(xv, s[k], rs[k]);
                 const float rq = rint_ste(q);
-                float xi = rq + z[e];
+                float xi = rq + z[k];
                 if (!EX) xi = rnd<T>(xi);
                 const bool m = (xi >= 0.f) && (xi <= qmax);
-                float xd = __builtin_amdgcn_fmed3f(xi, 0.f, qmax) - z[e];
+                float xd = __builtin_amdgcn_fmed3f(xi, 0.f, qmax) - z[k];
                 if (!EX) xd = rnd<T>(xd);
                 // outside the grid the quotient drops out; rq - rq is 0, or NaN when the level is NaN
                 acc[e] += gv * (xd - (m ? q : rq - rq));
-                nmx[e] += (xv == cmx[e]) ? 1 : 0;
-                nmn[e] += (xv == cmn[e]) ? 1 : 0;
-                o.e[e] = direct_out<T>(pb.e[e], gv, s[e], rs[e], m, NANS ? from_f<T>(0.f / s[e]) : from_f<T>(0.f));
+                nmx[e] += (xv == cmx[k]) ? 1 : 0;
+                nmn[e] += (xv == cmn[k]) ? 1 : 0;
+                o.e[e] = direct_out<T>(pb.e[e], gv, s[k], rs[k], m, NANS ? from_f<T>(0.f / s[k]) : from_f<T>(0.f));
             }
             st_pack<T, VEC>(dx + r * C + col0, o);
         };
@@ -342,13 +346,16 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
     const int tid = threadIdx.x;
     if (tid == 0) npairs = 0;
     __syncthreads();
-    // per-channel fold, 256 channels at a time: thread (w, c) sums chunks w, w + 4, ... of channel c
-    for (int c0 = 0; c0 < W; c0 += 256) {
-        const int c = tid & 255, w = tid >> 8;
+    // per-channel fold, TW = blockDim.x / 4 channels at a time: thread (w, c) sums chunks w, w + 4, ... of channel c
+    const int TW = blockDim.x >> 2, nwaves = blockDim.x >> 6;
+    for (int c0 = 0; c0 < W; c0 += TW) {
+        const int c = tid % TW, w = tid / TW;
         const bool valid = c0 + c < W;
         float acc[3] = {0.f, 0.f, 0.f};
-        if (valid) {
-            const float* p = part + st + c0 + c;
+        {
+            // every load is unconditional (an out-of-range chunk or channel re-reads a valid element and is zeroed
+            // afterwards): guarded loads would be issued one by one behind a branch each
+            const float* p = part + st + (valid ? c0 + c : 0);
             for (int j0 = w; j0 < nchunk; j0 += 64) {
                 float v[3][16];
 #pragma unroll
@@ -356,8 +363,13 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
                         const int j = j0 + 4 * u;
-                        v[k][u] = j < nchunk ? p[((long long)k * nchunk + j) * C] : 0.f;
+                        v[k][u] = p[((long long)k * nchunk + (j < nchunk ? j : nchunk - 1)) * C];
                     }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (!valid || j0 + 4 * u >= nchunk) v[k][u] = 0.f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     acc[k] += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7])) +
@@ -402,7 +414,7 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
     const bool live = s_raw >= lo && s_raw <= kClipHi;
     const float d = live ? acc[0] / qmax : 0.f;
     const bool mass = npairs > kPairMax;
-    for (int c = tid; c < W; c += 1024) {
+    for (int c = tid; c < W; c += blockDim.x) {
         const float hx = tot[1][c] > 0.f ? (d / acc[1]) / tot[1][c] : 0.f;
         const float hn = tot[2][c] > 0.f ? (-d / acc[2]) / tot[2][c] : 0.f;
         shr[0][c] = hx;
@@ -415,11 +427,11 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
         return;
     }
     __syncthreads();
-    // sparse correction: wave v takes pairs v, v + 16, ...; its lanes scan the rows of the pair's chunk
+    // sparse correction: wave v takes pairs v, v + nwaves, ...; its lanes scan the rows of the pair's chunk
     const T* __restrict__ x = static_cast<const T*>(sb.x);
     T* __restrict__ dx = static_cast<T*>(sb.dx);
     const int lane = tid & 63;
-    for (int i = tid >> 6; i < npairs; i += 16) {
+    for (int i = tid >> 6; i < npairs; i += nwaves) {
         const int e = pairs[i];
         const int j = e >> 12, c = (e >> 2) & 1023;
         const float hx = shr[0][c], hn = shr[1][c];
@@ -591,8 +603,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // (needs clusters of at most kClusterMax channels that cover every channel, and the flag word behind the workspace).
 template <typename T>
 static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const int* starts, int ncl, long long covered,
-                               int nchunk, long long R, long long C, int n_bits, int phase, bool merged, hipStream_t stream,
-                               const char* who) {
+                               int nchunk, long long R, long long C, int n_bits, int phase, bool merged, bool uniform,
+                               hipStream_t stream, const char* who) {
     constexpr int N = VecOf<T>::N;
     bool vec_ok = (C % N == 0);
     for (int i = 0; i < n; ++i) {
@@ -617,14 +629,19 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
     }
     const int flagged = merged ? 1 : 0;
     if (phase != 2) {
-        if (vec_ok) hipLaunchKernelGGL((k_colbwd_stream<T, N>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
-        else hipLaunchKernelGGL((k_colbwd_stream<T, 1>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
+        if (vec_ok && uniform) hipLaunchKernelGGL((k_colbwd_stream<T, N, true>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
+        else if (vec_ok) hipLaunchKernelGGL((k_colbwd_stream<T, N, false>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
+        else hipLaunchKernelGGL((k_colbwd_stream<T, 1, true>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
         if (!merged)
             hipLaunchKernelGGL(k_colbwd_fold, dim3((unsigned)((C + 63) / 64), 3, n), block, 0, stream, slabs, nchunk, (int)C);
     }
     if (phase != 1) {
         if (merged) {
-            hipLaunchKernelGGL((k_colbwd_cluster<T>), dim3(ncl, 1, n), dim3(1024), 0, stream, slabs, nchunk, R, (int)C, rpc, starts, qmax);
+            // four chunk sequences x a tile of the cluster's channels (64 .. 256, a multiple of 64) per block
+            long long tw = (covered / (ncl > 0 ? ncl : 1) + 63) / 64 * 64;
+            tw = tw < 64 ? 64 : (tw > 256 ? 256 : tw);
+            hipLaunchKernelGGL((k_colbwd_cluster<T>), dim3(ncl, 1, n), dim3((unsigned)(4 * tw)), 0, stream, slabs, nchunk, R, (int)C, rpc,
+                               starts, qmax);
         } else {
             const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
             hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk, cluster_slices(C, nblk), n), block, 0, stream, slabs, nchunk, (int)C,
@@ -657,10 +674,10 @@ extern "C" int miq_colquant_bwd(const void* grad_out, const void* x, const void*
     slabs.s[0] = BwdSlab{x, grad_out, scale, rzp, kmin, kmax, chan_min, chan_max, dx, workspace};
     if (dtype == MIQ_F32)
         return colquant_bwd_launch<float>(slabs, 1, chan_min != nullptr, starts, n_clusters, covered, nchunk, R, C, n_bits, phase,
-                                          false, (hipStream_t)stream, "miq_colquant_bwd");
+                                          false, false, (hipStream_t)stream, "miq_colquant_bwd");
     if (dtype == MIQ_F16)
         return colquant_bwd_launch<__half>(slabs, 1, chan_min != nullptr, starts, n_clusters, covered, nchunk, R, C, n_bits, phase,
-                                           false, (hipStream_t)stream, "miq_colquant_bwd");
+                                           false, false, (hipStream_t)stream, "miq_colquant_bwd");
     miq_set_error("miq_colquant_bwd: unsupported dtype %d", dtype);
     return -22;
 }
@@ -702,9 +719,11 @@ extern "C" int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const
     }
     const int nchunk = miq_colstat_chunks(R, C, dtype);
     const bool merged = cluster_size > 0 && cluster_size <= kClusterMax && covered == C;
+    // every 16-byte pack of channels inside one cluster: one parameter set per lane in the streaming kernel
+    const bool uniform = cluster_size > 0 && covered == C && cluster_size % (dtype == MIQ_F16 ? 8 : 4) == 0;
     if (dtype == MIQ_F32)
-        return colquant_bwd_launch<float>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged,
+        return colquant_bwd_launch<float>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged, uniform,
                                           (hipStream_t)stream, "miq_act_fresh_quant_bwd");
-    return colquant_bwd_launch<__half>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged,
+    return colquant_bwd_launch<__half>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged, uniform,
                                        (hipStream_t)stream, "miq_act_fresh_quant_bwd");
 }

@@ -132,25 +132,36 @@ def main():
     T = 2048
     for dt, es in ((f32, 4), (f16, 2)):
         for C, counts in ((4096, [128] * 32), (11008, [344] * 32)):
-            copies = max(2, int(600e6 // (T * C * es * 2)) + 1)
+            copies = max(3, (int(600e6 // (T * C * es * 2)) + 3) // 3 * 3)
             xs = [torch.randn(T, C, device=DEV, dtype=dt) for _ in range(copies)]
             gs = [torch.randn(T, C, device=DEV, dtype=dt) * 1e-3 for _ in range(copies)]
             lay = F.ClusterLayout.get(counts, C, torch.device(DEV))
             n = T * C * es * copies
             saved = []
 
-            def fwd():
+            def fwd():  # one slab per call: the shape of a site that stands alone in a block
                 saved.clear()
                 for x in xs:
-                    saved.append(F.act_calib_quant_fwd(x, 4, "ema_minmax", lay)[2])
+                    saved.append(F.act_fresh_quant_fwd([x], 4, lay)[2])
 
             def bwd():
-                for x, g, st in zip(xs, gs, saved):
-                    F.colquant_bwd(g, x, st["scale"], st["rzp"], 4, route=(st["chan_min"], st["chan_max"], st["cmin"], st["cmax"], lay))
+                for x, g, vecs in zip(xs, gs, saved):
+                    F.act_fresh_quant_bwd([g], [x], vecs, 4, lay)
+
+            saved3 = []
+
+            def fwd3():  # three slabs per call: the q / k / v sites of a block
+                saved3.clear()
+                for i in range(0, len(xs) - 2, 3):
+                    saved3.append(F.act_fresh_quant_fwd(xs[i:i + 3], 4, lay)[2])
+
+            def bwd3():
+                for j, i in enumerate(range(0, len(xs) - 2, 3)):
+                    F.act_fresh_quant_bwd(gs[i:i + 3], xs[i:i + 3], saved3[j], 4, lay)
 
             def evalq():
-                for x, st in zip(xs, saved):
-                    F.colquant_fwd(x, st["scale"], st["rzp"], 4)
+                for x, vecs in zip(xs, saved):
+                    F.colquant_fwd(x, vecs[0][2], vecs[0][4], 4)
 
             idx = torch.randperm(C, device=DEV).to(torch.int32)
 
@@ -159,8 +170,10 @@ def main():
                     F.gather_lastdim(x, idx)
 
             tag = f"{'f32' if es == 4 else 'f16'}.{T}x{C}"
-            for name, fn, mult in (("C2.act_calibrate_quantize", fwd, 3), ("C2.act_backward", bwd, 3), ("C2.act_eval_quantize", evalq, 2),
-                                   ("C2.reorder_gather", gather, 2)):
+            n3 = T * C * es * (copies // 3 * 3)
+            for name, fn, mult in (("C2.act_calibrate_quantize", fwd, 3), ("C2.act_backward", bwd, 3),
+                                   ("C2.act_calibrate_quantize_x3", fwd3, 3 * n3 / n), ("C2.act_backward_x3", bwd3, 3 * n3 / n),
+                                   ("C2.act_eval_quantize", evalq, 2), ("C2.reorder_gather", gather, 2)):
                 t = time_graph(fn)
                 gbs = mult * n / t / 1e9
                 res[f"{name}.{tag}"] = {"GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK, 4), "us_per_tensor": round(t / copies * 1e6, 1)}

@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 FAMILY = [(r"k_uniform_fwd", "rowquant_fwd"), (r"k_uniform_bwd", "rowquant_bwd"),
-          (r"k_colstat|k_cluster_scale|k_colquant_fwd", "act_calib_quant_fwd"), (r"k_colbwd", "act_bwd"),
+          (r"k_colstat|k_cluster_scale|k_colquant_fwd|k_colquant_slots", "act_calib_quant_fwd"), (r"k_colbwd", "act_bwd"),
           (r"k_gather", "gather")]
 
 
