@@ -135,6 +135,10 @@ int miq_colquant_fwd(const void* x, const void* scale, const void* rzp, void* ou
  * workspace has (3*nchunk + 5)*C floats with nchunk = miq_colstat_chunks(R, C, dtype).
  * x and grad_out are read once (dx receives the direct path in the same pass); the routed shares
  * are then added in place to the few elements that attain a cluster extreme.
+ * flat_ties: how tied extremes share the scale gradient.  0: per channel, then per row (the statistics of a cluster are
+ * an amax over channels of a per-channel amax over rows, quantizer.py:190-210); 1: evenly among all tied elements of the
+ * cluster (per-tensor statistics are one reduction over all elements: torch.min(x) / torch.max(x), quantizer.py:222-223,
+ * and amin / amax over every axis when no cluster axis is set).
  * phase 0 runs everything.  Data-parallel callers that quantize with GLOBAL-batch statistics split
  * the call: phase 1 writes the direct path into dx and leaves the per-channel sums [dS, #max, #min]
  * in workspace[3*nchunk*C : (3*nchunk + 3)*C] (to be summed over ranks by the caller), phase 2
@@ -143,7 +147,7 @@ int miq_colquant_fwd(const void* x, const void* scale, const void* rzp, void* ou
 int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, const void* rzp,
                      const float* chan_min, const float* chan_max, const void* kmin, const void* kmax,
                      const int* starts, int n_clusters, int64_t covered, float* workspace, int nchunk,
-                     void* dx, int64_t R, int64_t C, int n_bits, int phase, int dtype, void* stream);
+                     void* dx, int64_t R, int64_t C, int n_bits, int phase, int flat_ties, int dtype, void* stream);
 
 /*
  * The calibrating static quantizer in one call: the whole of UniformAffineQuantizer.forward in
@@ -183,6 +187,7 @@ int miq_act_calib_quant_fwd(const void* x, const void* cached_min, const void* c
  * channel the chunk fold, the shares and the (usually sparse) correction run in one launch (3 launches in all, the
  * last one a no-op unless a cluster has mass ties), otherwise in the four of miq_colquant_bwd; same bits either way.
  *   starts        [n_clusters + 1] int32 prefix sums of the cluster sizes on the device
+ *   flat_ties     as for miq_colquant_bwd
  *   workspace     miq_act_fresh_bwd_workspace(n, R, C, dtype) BYTES, 16-byte aligned, no initialisation needed
  */
 int64_t miq_act_fresh_workspace(int n, int64_t C, int n_clusters, int64_t covered);
@@ -192,7 +197,7 @@ int miq_act_fresh_quant_fwd(int n, const void* const* x, int64_t cluster_size, c
 int64_t miq_act_fresh_bwd_workspace(int n, int64_t R, int64_t C, int dtype);
 int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const void* const* x, const void* const* stats,
                             int64_t cluster_size, const int* starts, int n_clusters, int64_t covered, int n_bits,
-                            void* workspace, void* const* dx, int64_t R, int64_t C, int dtype, void* stream);
+                            void* workspace, void* const* dx, int64_t R, int64_t C, int flat_ties, int dtype, void* stream);
 
 /*
  * miq_act_calib_quant_fwd for callers that cannot allocate device memory (code under HIP graph capture,

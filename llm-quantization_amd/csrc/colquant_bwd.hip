@@ -5,10 +5,13 @@
 //   direct path      dx  = (g*s)*m/s
 //   scale path       dS_k = sum over the cluster slab of g*(xd - m*x/s)   (0 when the scale clamp is active)
 //                    d_kmax = dS_k/qmax, d_kmin = -dS_k/qmax
-//   routing          the cluster max is an amax over channels of the per-channel amax over rows;
-//                    autograd splits evenly among tied channels, then evenly among tied rows:
-//                    every element equal to its channel max, in a channel whose max equals the
+//   routing          per cluster the maximum is an amax over channels of the per-channel amax over rows
+//                    (quantizer.py:190-210): autograd splits evenly among tied channels, then evenly among tied
+//                    rows, so every element equal to its channel max, in a channel whose max equals the
 //                    cluster max, receives (d_kmax / #tied channels) / #tied rows (same for min).
+//                    Per-tensor statistics are ONE reduction over all elements (torch.min(x) / torch.max(x),
+//                    quantizer.py:222-223, and amin / amax over every axis when no cluster axis is set):
+//                    autograd then splits evenly among all tied elements (`flat`: d_kmax / #tied elements).
 // One streaming pass plus a sparse correction:
 //   k_colbwd_stream   reads x and g once, writes the direct path into dx and leaves per (row chunk,
 //                     channel) partial sums of dS and of the number of elements at the channel max / min
@@ -239,7 +242,7 @@ k_colbwd_fold(BwdSlabs slabs, int nchunk, int C) {
 // statistics) is spread over up to 16 blocks instead of one block walking all channels.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ starts, int ncl, float qmax) {
+k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ starts, int ncl, float qmax, int flat) {
     __shared__ float lds[48];
     const BwdSlab& sb = slabs.s[blockIdx.z];
     const float* __restrict__ sums = sb.ws + 3ll * nchunk * C;
@@ -300,8 +303,8 @@ k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ start
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             acc[0] += ds[u];
-            acc[1] += ax[u] ? 1.f : 0.f;
-            acc[2] += an[u] ? 1.f : 0.f;
+            acc[1] += ax[u] ? (flat ? colsum(1, c + 256 * u) : 1.f) : 0.f;
+            acc[2] += an[u] ? (flat ? colsum(2, c + 256 * u) : 1.f) : 0.f;
         }
     }
     team_sum<256, 3>(acc, lds);
@@ -309,12 +312,12 @@ k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ start
     const bool live = s_raw >= lo && s_raw <= kClipHi;
     const float d = live ? acc[0] / qmax : 0.f;
     if (has0) {
-        share_max[first] = ax0 ? (d / acc[1]) / n1 : 0.f;
-        share_min[first] = an0 ? (-d / acc[2]) / n2 : 0.f;
+        share_max[first] = ax0 ? (flat ? d / acc[1] : (d / acc[1]) / n1) : 0.f;
+        share_min[first] = an0 ? (flat ? -d / acc[2] : (-d / acc[2]) / n2) : 0.f;
     }
     for (int c = first + step; c < en; c += step) {
-        share_max[c] = at_max(c, mx) ? (d / acc[1]) / colsum(1, c) : 0.f;
-        share_min[c] = at_min(c, mn) ? (-d / acc[2]) / colsum(2, c) : 0.f;
+        share_max[c] = at_max(c, mx) ? (flat ? d / acc[1] : (d / acc[1]) / colsum(1, c)) : 0.f;
+        share_min[c] = at_min(c, mn) ? (flat ? -d / acc[2] : (-d / acc[2]) / colsum(2, c)) : 0.f;
     }
 }
 
@@ -329,7 +332,8 @@ constexpr int kClusterMax = 1024;
 constexpr int kPairMax = 64;
 template <typename T>
 __global__ void __launch_bounds__(1024)
-k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, const int* __restrict__ starts, float qmax) {
+k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, const int* __restrict__ starts, float qmax,
+                 int flat) {
     __shared__ float part_l[3][4][256];
     __shared__ float tot[3][kClusterMax];
     __shared__ float shr[2][kClusterMax];
@@ -403,8 +407,8 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
                 const int cc = c + 256 * u;
                 const bool in = cc < W;
                 acc[0] += in ? tot[0][cc] : 0.f;
-                acc[1] += (in && tot[1][cc] > 0.f) ? 1.f : 0.f;
-                acc[2] += (in && tot[2][cc] > 0.f) ? 1.f : 0.f;
+                acc[1] += (in && tot[1][cc] > 0.f) ? (flat ? tot[1][cc] : 1.f) : 0.f;
+                acc[2] += (in && tot[2][cc] > 0.f) ? (flat ? tot[2][cc] : 1.f) : 0.f;
             }
         }
     }
@@ -415,8 +419,8 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
     const float d = live ? acc[0] / qmax : 0.f;
     const bool mass = npairs > kPairMax;
     for (int c = tid; c < W; c += blockDim.x) {
-        const float hx = tot[1][c] > 0.f ? (d / acc[1]) / tot[1][c] : 0.f;
-        const float hn = tot[2][c] > 0.f ? (-d / acc[2]) / tot[2][c] : 0.f;
+        const float hx = tot[1][c] > 0.f ? (flat ? d / acc[1] : (d / acc[1]) / tot[1][c]) : 0.f;
+        const float hn = tot[2][c] > 0.f ? (flat ? -d / acc[2] : (-d / acc[2]) / tot[2][c]) : 0.f;
         shr[0][c] = hx;
         shr[1][c] = hn;
         share_max[st + c] = mass ? hx : 0.f;
@@ -604,7 +608,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 template <typename T>
 static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const int* starts, int ncl, long long covered,
                                int nchunk, long long R, long long C, int n_bits, int phase, bool merged, bool uniform,
-                               hipStream_t stream, const char* who) {
+                               int flat, hipStream_t stream, const char* who) {
     constexpr int N = VecOf<T>::N;
     bool vec_ok = (C % N == 0);
     for (int i = 0; i < n; ++i) {
@@ -641,11 +645,11 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
             long long tw = (covered / (ncl > 0 ? ncl : 1) + 63) / 64 * 64;
             tw = tw < 64 ? 64 : (tw > 256 ? 256 : tw);
             hipLaunchKernelGGL((k_colbwd_cluster<T>), dim3(ncl, 1, n), dim3((unsigned)(4 * tw)), 0, stream, slabs, nchunk, R, (int)C, rpc,
-                               starts, qmax);
+                               starts, qmax, flat);
         } else {
             const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
             hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk, cluster_slices(C, nblk), n), block, 0, stream, slabs, nchunk, (int)C,
-                               starts, ncl, qmax);
+                               starts, ncl, qmax, flat);
         }
         if (vec_ok) hipLaunchKernelGGL((k_colbwd_fixup<T, N>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);
         else hipLaunchKernelGGL((k_colbwd_fixup<T, 1>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);
@@ -661,7 +665,7 @@ using namespace miq;
 extern "C" int miq_colquant_bwd(const void* grad_out, const void* x, const void* scale, const void* rzp,
                                 const float* chan_min, const float* chan_max, const void* kmin, const void* kmax,
                                 const int* starts, int n_clusters, int64_t covered, float* workspace, int nchunk,
-                                void* dx, int64_t R, int64_t C, int n_bits, int phase, int dtype, void* stream) {
+                                void* dx, int64_t R, int64_t C, int n_bits, int phase, int flat_ties, int dtype, void* stream) {
     if (R == 0 || C == 0) return 0;
     MIQ_CHECK_ARG(grad_out && x && scale && rzp && dx && R > 0 && C > 0 && C < (1ll << 31),
                   "miq_colquant_bwd: null pointer or bad shape");
@@ -674,10 +678,10 @@ extern "C" int miq_colquant_bwd(const void* grad_out, const void* x, const void*
     slabs.s[0] = BwdSlab{x, grad_out, scale, rzp, kmin, kmax, chan_min, chan_max, dx, workspace};
     if (dtype == MIQ_F32)
         return colquant_bwd_launch<float>(slabs, 1, chan_min != nullptr, starts, n_clusters, covered, nchunk, R, C, n_bits, phase,
-                                          false, false, (hipStream_t)stream, "miq_colquant_bwd");
+                                          false, false, flat_ties ? 1 : 0, (hipStream_t)stream, "miq_colquant_bwd");
     if (dtype == MIQ_F16)
         return colquant_bwd_launch<__half>(slabs, 1, chan_min != nullptr, starts, n_clusters, covered, nchunk, R, C, n_bits, phase,
-                                           false, false, (hipStream_t)stream, "miq_colquant_bwd");
+                                           false, false, flat_ties ? 1 : 0, (hipStream_t)stream, "miq_colquant_bwd");
     miq_set_error("miq_colquant_bwd: unsupported dtype %d", dtype);
     return -22;
 }
@@ -696,7 +700,8 @@ extern "C" int64_t miq_act_fresh_bwd_workspace(int n, int64_t R, int64_t C, int 
 
 extern "C" int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const void* const* x, const void* const* stats,
                                        int64_t cluster_size, const int* starts, int n_clusters, int64_t covered, int n_bits,
-                                       void* workspace, void* const* dx, int64_t R, int64_t C, int dtype, void* stream) {
+                                       void* workspace, void* const* dx, int64_t R, int64_t C, int flat_ties, int dtype,
+                                       void* stream) {
     if (n == 0 || R == 0 || C == 0) return 0;
     MIQ_CHECK_ARG(n > 0 && n <= kMaxBwdSlabs, "miq_act_fresh_quant_bwd: %d slabs (1..%d per call)", n, kMaxBwdSlabs);
     MIQ_CHECK_ARG(grad_out && x && stats && dx && starts && workspace && R > 0 && C > 0 && C < (1ll << 31),
@@ -723,7 +728,7 @@ extern "C" int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const
     const bool uniform = cluster_size > 0 && covered == C && cluster_size % (dtype == MIQ_F16 ? 8 : 4) == 0;
     if (dtype == MIQ_F32)
         return colquant_bwd_launch<float>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged, uniform,
-                                          (hipStream_t)stream, "miq_act_fresh_quant_bwd");
+                                          flat_ties ? 1 : 0, (hipStream_t)stream, "miq_act_fresh_quant_bwd");
     return colquant_bwd_launch<__half>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged, uniform,
-                                       (hipStream_t)stream, "miq_act_fresh_quant_bwd");
+                                       flat_ties ? 1 : 0, (hipStream_t)stream, "miq_act_fresh_quant_bwd");
 }

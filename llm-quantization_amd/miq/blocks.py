@@ -215,7 +215,7 @@ class _BlockBase(nn.Module):
     def _truncate_scales(self):
         # the smoothing scales are parameters of the block itself (init_let registers them): the list is rebuilt only
         # when that dict changes, not by a walk over the module tree on every step
-        key = tuple(self._parameters)
+        key = tuple((n, id(q)) for n, q in self._parameters.items())  # init_let may re-register a name with a new tensor
         cache = self.__dict__.get("_smooth_scale_cache")
         if cache is None or cache[0] != key:
             cache = (key, [p for n, p in self.named_parameters() if "smooth_scale" in n])

@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import functional as MF
 from . import reorder_utils as R
-from .dist import DPContext, allreduce_mean_grads, broadcast_from, owner_of, shard_range
+from .dist import DPContext, allreduce_mean_grads, broadcast_from, sample_owner
 from .int_linear import QuantLinear
 from .int_matmul import QuantMatMul
 from .omni_norm import OmniLayerNorm
@@ -55,6 +55,9 @@ class CalibConfig:
     aug_loss: bool = False                 # add the MSE against the fp block applied to the QUANTIZED model's inputs
     fused_adamw: bool = False              # torch's fused AdamW: no host synchronisation in GradScaler.step, but its
                                            # arithmetic differs in the last bits from the default implementation
+    autocast_passes: bool = True           # run the full-precision target pass and the final propagation pass under fp16
+                                           # autocast whatever deactive_amp says, as the reference does
+                                           # (quantize/omniquant.py:402, :583); False keeps them in the training precision
 
 
 class LossScaler:
@@ -255,7 +258,8 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
     """Calibrate ONE block in place.
 
     quant_inps / fp_inps: [n_local, T, H] tensors holding THIS rank's shard of the calibration
-    samples (all samples when dp is None); both are overwritten with the block's outputs, as the
+    samples (all samples when dp is None; with data parallelism the samples dist.sample_indices(nsamples, rank,
+    world), i.e. rank, rank + world, ...); both are overwritten with the block's outputs, as the
     reference does.  ``dims`` = (hidden, ffn, heads) is needed when reordering.  ``resume_state``: the
     layer's entry of a previous run's omni_parameters (reference ``--resume``, omniquant.py:452-453).
     Returns a dict with the per-step losses / gradient norms and the reorder indices.
@@ -305,11 +309,12 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
     lap("reorder")
     # ---- full-precision targets -------------------------------------------------------------
     qlayer.set_quant_state(weight_quant=False, act_quant=False)
+    pass_amp = (use_amp or cfg.autocast_passes) and dev.type == "cuda"
     if cfg.epochs > 0:
-        if not use_amp:
+        if not pass_amp:
             with torch.no_grad():
                 qlayer.float()  # fp32 path: without autocast the block must match the fp32 activations
-        with torch.no_grad(), (torch.autocast("cuda", dtype=torch.float16) if use_amp else nullcontext()):
+        with torch.no_grad(), (torch.autocast("cuda", dtype=torch.float16) if pass_amp else nullcontext()):
             if cfg.aug_loss:  # omniquant.py:405-406
                 fp_inps_2 = torch.empty_like(fp_inps)
             for j in range(n_local):
@@ -340,7 +345,13 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                                       fused=True if (cfg.fused_adamw and dev.type == "cuda") else None)
         scaler = LossScaler("cuda" if dev.type == "cuda" else "cpu")
         buf = None
-        steps_per_epoch = n_local // cfg.batch_size
+        # every rank takes the same number of steps (each one holds a collective): the smallest shard decides
+        steps_per_epoch = ((n_total // dp.world) if dp.active else n_local) // cfg.batch_size
+        if steps_per_epoch * cfg.batch_size > n_local:
+            raise ValueError(f"rank {dp.rank} holds {n_local} samples, fewer than its share of nsamples={n_total} over {dp.world} ranks")
+        if dp.active and logger is not None and steps_per_epoch * cfg.batch_size * dp.world != n_total:
+            logger.info(f"{n_total - steps_per_epoch * cfg.batch_size * dp.world} samples per epoch are not trained on "
+                        f"(nsamples is not a multiple of ranks x batch_size)")
         loss_size_coef = cfg.loss_size_coef
         # per-step loss / gradient norm stay on the device until the end of the epoch
         trace = torch.zeros((2, max(1, steps_per_epoch)), dtype=torch.float32, device=dev)
@@ -415,19 +426,20 @@ def finalize_layer(qlayer, quant_inps, attention_mask, cfg: CalibConfig, dp: Opt
     _set_dp(qlayer, None)  # the propagation pass is replicated, not synchronised
     if cfg.epochs <= 0:
         qlayer.half()
-    cast = (torch.autocast("cuda", dtype=torch.float16) if (use_amp and cfg.epochs > 0) else nullcontext())
+    pass_amp = (use_amp or cfg.autocast_passes) and quant_inps.device.type == "cuda"
+    cast = (torch.autocast("cuda", dtype=torch.float16) if (pass_amp and cfg.epochs > 0) else nullcontext())
     with torch.no_grad(), cast:
         if dp.active:
-            a, _b = shard_range(n_total, dp.rank, dp.world)
-            tmp = torch.empty_like(quant_inps[0])
+            # global sample order 0, 1, 2, ...: sample j lives on rank j % world at local position j // world
+            tmp = torch.empty(quant_inps.shape[1:], dtype=quant_inps.dtype, device=quant_inps.device)
             for j in range(n_total):
-                own = owner_of(j, n_total, dp.world)
+                own, at = sample_owner(j, dp.world)
                 if own == dp.rank:
-                    tmp.copy_(quant_inps[j - a])
+                    tmp.copy_(quant_inps[at])
                 broadcast_from(tmp, own, dp)
                 y = qlayer(tmp.unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]
                 if own == dp.rank:
-                    quant_inps[j - a] = y
+                    quant_inps[at] = y
         else:
             for j in range(n_local):
                 quant_inps[j] = qlayer(quant_inps[j].unsqueeze(0), attention_mask=attention_mask, position_ids=position_ids)[0]

@@ -4,8 +4,8 @@
 The path has exactly two exchange steps per optimizer step, both latency-bound small messages:
   * one all-reduce (SUM, then / world) of all LWC/LET(/n_bits) gradients packed in one flat fp32 buffer;
   * optionally, per activation-quantizer call, one MAX all-reduce of the packed [-min, max] channel
-    statistics so that every rank derives the scale of the GLOBAL batch (this makes W ranks with
-    batch 1 equal to the reference run with --batch_size W).
+    statistics so that every rank derives the scale of the GLOBAL batch.  With the samples dealt out round-robin
+    (sample_indices) the W ranks' step j then is batch j of the reference run with --batch_size W.
 Sample shards and weight-row shards need no communication.
 """
 from __future__ import annotations
@@ -50,37 +50,53 @@ def owner_of(index: int, n: int, world: int) -> int:
     return extra + (index - cut) // base if base else world - 1
 
 
-def allreduce_mean_grads(params: Iterable[torch.nn.Parameter], ctx: DPContext, buf: Optional[torch.Tensor] = None):
-    """Average the gradients of ``params`` across ranks with ONE collective on a packed fp32 buffer.
-    Parameters without a gradient contribute zeros (and receive the mean of the others)."""
+def sample_indices(n: int, rank: int, world: int):
+    """Calibration samples held by ``rank``: rank, rank + world, ...  Strided on purpose: the ranks' local step j then
+    works on samples j * world .. j * world + world - 1, which is batch j of the reference run with
+    --batch_size world (quantize/omniquant.py:502-510)."""
+    return range(rank, n, world)
+
+
+def sample_owner(index: int, world: int):
+    """(rank, local position) of calibration sample ``index`` under sample_indices()."""
+    return index % world, index // world
+
+
+class GradBucket:
+    """One flat fp32 buffer with a view per parameter: packing and unpacking are one multi-tensor copy each."""
+
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.shapes = [(p.shape, p.dtype, p.device) for p in params]
+        n = sum(p.numel() for p in params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=params[0].device)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+
+    def fits(self, params):
+        return len(params) == len(self.shapes) and all((p.shape, p.dtype, p.device) == s for p, s in zip(params, self.shapes))
+
+
+def allreduce_mean_grads(params: Iterable[torch.nn.Parameter], ctx: DPContext, buf: Optional[GradBucket] = None):
+    """Average the gradients of ``params`` across ranks with ONE collective on a packed fp32 buffer (pack, all-reduce,
+    scale, unpack: four launches however many parameters there are).  Parameters without a gradient contribute
+    zeros (and receive the mean of the others).  Returns the bucket for reuse by the next step."""
     if not ctx.active:
         return buf
     params = [p for p in params]
     if not params:
         return buf
-    n = sum(p.numel() for p in params)
-    dev = params[0].device
-    if buf is None or buf.numel() != n or buf.device != dev:
-        buf = torch.empty(n, dtype=torch.float32, device=dev)
-    off = 0
+    if buf is None or not buf.fits(params):
+        buf = GradBucket(params)
     for p in params:
-        k = p.numel()
         if p.grad is None:
-            buf[off:off + k].zero_()
-        else:
-            buf[off:off + k].copy_(p.grad.reshape(-1))
-        off += k
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
-    buf.div_(ctx.world)
-    off = 0
-    for p in params:
-        k = p.numel()
-        g = buf[off:off + k].reshape(p.shape).to(p.dtype)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
-        off += k
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
+    torch._foreach_copy_(buf.views, grads)
+    dist.all_reduce(buf.flat, op=dist.ReduceOp.SUM, group=ctx.group)
+    buf.flat.div_(ctx.world)
+    torch._foreach_copy_(grads, buf.views)
     return buf
 
 

@@ -202,6 +202,9 @@ class ClusterLayout:
     _cache = {}
 
     def __init__(self, counts, C: int, device):
+        # per-tensor statistics are one reduction over all elements: tied extremes share the scale gradient evenly,
+        # whereas the extremes of an explicit cluster are found per channel first (ties split per channel, then per row)
+        self.flat = counts is None
         if counts is None:
             counts = [C]
         counts = [int(c) for c in counts]
@@ -402,7 +405,7 @@ def act_fresh_quant_bwd(gs, xs, vecs, n_bits: int, layout: ClusterLayout):
     with L.on_device(dev):
         L.call("miq_act_fresh_quant_bwd", L.i32(n), _ptr_table(gs), _ptr_table(xs), _ptr_table(vecs), L.i64(layout.cluster_size),
                L.ptr(layout.starts), L.i32(layout.n_clusters), L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(ws),
-               _ptr_table(dxs), L.i64(R), L.i64(C), L.i32(code), L.stream_of(xs[0]))
+               _ptr_table(dxs), L.i64(R), L.i64(C), L.i32(int(layout.flat)), L.i32(code), L.stream_of(xs[0]))
     return dxs
 
 
@@ -413,8 +416,10 @@ def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
     R, C = x2d.shape
     dx = torch.empty_like(x2d)
     nchunk = colstat_chunks(R, C, x2d.dtype)
+    flat = L.i32(0)
     if route is not None:
         chan_min, chan_max, kmin, kmax, layout = route
+        flat = L.i32(int(layout.flat))
         ws = torch.empty((3 * nchunk + 5) * C, dtype=torch.float32, device=dev)
         args = (L.ptr(chan_min), L.ptr(chan_max), L.ptr(kmin), L.ptr(kmax), L.ptr(layout.starts),
                 L.i32(layout.n_clusters), L.i64(layout.covered), L.ptr(ws))
@@ -425,11 +430,11 @@ def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
     with L.on_device(dev):
         if route is not None and dp is not None and dp.active and dp.sync_stats:
             import torch.distributed as tdist
-            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(1), code, st)
+            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(1), flat, code, st)
             tdist.all_reduce(ws[3 * nchunk * C:(3 * nchunk + 3) * C], group=dp.group)  # [dS, #max, #min] per channel
-            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(2), code, st)
+            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(2), flat, code, st)
         else:
-            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(0), code, st)
+            L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(0), flat, code, st)
     return dx
 
 

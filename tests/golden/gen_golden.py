@@ -538,6 +538,7 @@ def main():
             "act": gen_act, "reorder": gen_reorder}
     fams["block"] = lambda _ref: gen_block(args.ref)
     fams["block_llama"] = lambda _ref: gen_block_llama(args.ref)
+    fams["block_llama_gqa"] = lambda _ref: gen_block_llama_gqa(args.ref)
     fams["act_stats"] = lambda _ref: gen_act_stats(args.ref)
     for fam, fn in fams.items():
         if args.only and fam not in args.only.split(","):
@@ -681,8 +682,8 @@ def gen_block(ref_root):
                     qlayer.register_parameter(f"{pairs[key]}_smooth_scale", torch.nn.Parameter(scale))
     with torch.no_grad():
         qlayer.float()
-    optimizer = torch.optim.AdamW([{"params": qlayer.let_parameters(True), "lr": args.let_lr},
-                                   {"params": qlayer.lwc_parameters(), "lr": args.lwc_lr}], weight_decay=args.wd)
+    optimizer = torch.optim.AdamW([{"params": list(qlayer.let_parameters(True)), "lr": args.let_lr},
+                                   {"params": list(qlayer.lwc_parameters()), "lr": args.lwc_lr}], weight_decay=args.wd)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -736,6 +737,17 @@ def gen_block(ref_root):
 # position_ids is the integer 1, which today's apply_rotary_pos_emb takes as its unsqueeze_dim.
 # ---------------------------------------------------------------------------------------------
 def gen_block_llama(ref_root):
+    return {"llama_tiny_w4a4_pertensor": _llama_block_case(kv_heads=4, let=True)}
+
+
+# Grouped-query attention (the Llama-2-70B layout: fewer key / value heads than query heads, repeat_kv in
+# models/int_llama_layer.py:130-137), 2 KV heads for 4 query heads.  LET off: the reference's smooth_q_k_*
+# assumes as many KV heads as heads (models/transformation.py:62-69), so only the clipping factors train.
+def gen_block_llama_gqa(ref_root):
+    return {"llama_tiny_gqa_w4a4_nolet": _llama_block_case(kv_heads=2, let=False)}
+
+
+def _llama_block_case(kv_heads, let):
     import types as _t
     import warnings
 
@@ -773,7 +785,7 @@ def gen_block_llama(ref_root):
     src = torch.nn.Module()
     src.self_attn = torch.nn.Module()
     a = src.self_attn
-    a.q_proj, a.k_proj, a.v_proj, a.o_proj = lin(H, H), lin(H, H), lin(H, H), lin(H, H)
+    a.q_proj, a.k_proj, a.v_proj, a.o_proj = lin(H, H), lin(H, kv_heads * hd), lin(H, kv_heads * hd), lin(H, H)
     a.rotary_emb = Rotary()
     src.mlp = torch.nn.Module()
     src.mlp.gate_proj, src.mlp.up_proj, src.mlp.down_proj = lin(H, Fd), lin(H, Fd), lin(Fd, H)
@@ -787,12 +799,12 @@ def gen_block_llama(ref_root):
                              "group_size": None, "lwc": True, "dynamic": True, "metric": "minmax", "target_bit": wbits},
         act_quant_params=dict(act), q_quant_params=dict(act), k_quant_params=dict(act), v_quant_params=dict(act),
         p_quant_params={"n_bits": 16, "metric": "fix0to1"},
-        let=True, alpha=0.5, let_lr=5e-3, lwc_lr=1e-2, wd=0.0, batch_size=1, nsamples=N, epochs=epochs)
-    config = _t.SimpleNamespace(hidden_size=H, num_attention_heads=heads, num_key_value_heads=heads,
+        let=let, alpha=0.5, let_lr=5e-3, lwc_lr=1e-2, wd=0.0, batch_size=1, nsamples=N, epochs=epochs)
+    config = _t.SimpleNamespace(hidden_size=H, num_attention_heads=heads, num_key_value_heads=kv_heads,
                                 max_position_embeddings=T, intermediate_size=Fd, hidden_act="silu")
     qlayer = QuantLlamaDecoderLayer(config, src, args)
     d = {"meta": {"H": H, "F": Fd, "heads": heads, "T": T, "N": N, "epochs": epochs, "wbits": wbits, "abits": abits,
-                  "theta": theta, "eps": eps}}
+                  "theta": theta, "eps": eps, "kv_heads": kv_heads, "let": let}}
     for n, m in (("q", a.q_proj), ("k", a.k_proj), ("v", a.v_proj), ("o", a.o_proj), ("gate", src.mlp.gate_proj),
                  ("up", src.mlp.up_proj), ("down", src.mlp.down_proj)):
         d[f"w_{n}"] = m.weight.detach().float().clone()
@@ -818,12 +830,13 @@ def gen_block_llama(ref_root):
             fp_inps[j] = qlayer(fp_inps[j].unsqueeze(0), attention_mask=mask, position_ids=position_ids)[0]
     d["fp_out"] = fp_inps.clone()
     qlayer.set_quant_state(weight_quant=False, act_quant=True)
-    qlayer.let = True
+    qlayer.let = let
     dtype = torch.float32
     pairs = {"q_proj": "qkv", "o_proj": "out", "up_proj": "fc1"}
-    qlayer.register_parameter("qkt_smooth_scale", torch.nn.Parameter(torch.ones(H, dtype=dtype)))
+    if let:
+        qlayer.register_parameter("qkt_smooth_scale", torch.nn.Parameter(torch.ones(H, dtype=dtype)))
     for name, module in qlayer.named_modules():
-        if isinstance(module, QuantLinear):
+        if let and isinstance(module, QuantLinear):
             for key in pairs:
                 if key in name:
                     actv = act_scales[f"{prefix}.{name}"].clamp(min=1e-5)
@@ -834,8 +847,8 @@ def gen_block_llama(ref_root):
                     qlayer.register_parameter(f"{pairs[key]}_smooth_scale", torch.nn.Parameter(scale))
     with torch.no_grad():
         qlayer.float()
-    optimizer = torch.optim.AdamW([{"params": qlayer.let_parameters(True), "lr": args.let_lr},
-                                   {"params": qlayer.lwc_parameters(), "lr": args.lwc_lr}], weight_decay=args.wd)
+    optimizer = torch.optim.AdamW([{"params": list(qlayer.let_parameters(True)), "lr": args.let_lr},
+                                   {"params": list(qlayer.lwc_parameters()), "lr": args.lwc_lr}], weight_decay=args.wd)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         loss_scaler = ref_utils.NativeScalerWithGradNormCount()
@@ -872,7 +885,7 @@ def gen_block_llama(ref_root):
         if isinstance(m, QuantLinear):
             d[f"wq_{name}"] = m.weight.detach().clone()
     d["omni_keys"] = list(qlayer.omni_state_dict().keys())
-    return {"llama_tiny_w4a4_pertensor": d}
+    return d
 
 
 # ---------------------------------------------------------------------------------------------

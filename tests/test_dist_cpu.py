@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 from miq import dist as D
 from miq import reorder_utils as R
-from miq.calibrate import LossScaler, sync_reorder_stats
+from miq.calibrate import CalibConfig, LossScaler, calibrate_layer, sync_reorder_stats
 
 
 def _free_port():
@@ -161,3 +161,103 @@ def test_weight_row_shards_cover_all_rows():
     got = torch.cat([out[r][0][2] for r in range(2)])
     assert torch.equal(got, w0)
     assert out[0][1][0] == 0 and out[1][1][1] == 7
+
+
+def test_sample_shards_are_dealt_round_robin():
+    """Rank r holds samples r, r + W, ...: local step j of the W ranks is the reference's batch j at --batch_size W."""
+    for n in (0, 1, 7, 128, 129):
+        for world in (1, 2, 3, 8):
+            seen = {}
+            for r in range(world):
+                for at, j in enumerate(D.sample_indices(n, r, world)):
+                    assert D.sample_owner(j, world) == (r, at)
+                    seen[j] = r
+            assert sorted(seen) == list(range(n))
+    assert [list(D.sample_indices(8, r, 2))[1] for r in range(2)] == [2, 3]  # step 1 of two ranks = samples {2, 3}
+
+
+class _StubBlock(torch.nn.Module):
+    """The part of a quantized block's interface that calibrate_layer drives, on plain CPU ops: one linear layer whose
+    weight is scaled by a trainable per-row factor (standing in for the clipping factors)."""
+
+    def __init__(self, h):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.weight = torch.nn.Parameter(torch.randn(h, h, generator=g) * 0.3, requires_grad=False)
+        self.upbound_factor = torch.nn.Parameter(torch.ones(h, 1))
+        self.calls = []
+
+    def forward(self, x, attention_mask=None, position_ids=None):
+        self.calls.append(float(x.sum()))
+        w = self.weight * self.upbound_factor if self.training_mode else self.weight
+        return (torch.tanh(x @ w.t()),)
+
+    training_mode = False
+    let = False
+
+    def set_quant_state(self, weight_quant=False, act_quant=False):
+        self.training_mode = act_quant
+
+    def smooth_and_quant_temporary(self): pass
+    def smooth_and_quant_inplace(self): pass
+    def clear_temp_variable(self): pass
+    def register_scales_and_zeros(self): pass
+    def act_quantizers(self): return []
+    def let_parameters(self, use_shift=True): return []
+    def lwc_parameters(self): return [self.upbound_factor]
+    def omni_parameters(self, use_shift=True): return [self.upbound_factor]
+    def omni_state_dict(self): return {"upbound_factor": self.upbound_factor.detach().clone()}
+
+
+def _samples(n, t, h):
+    return torch.randn(n, t, h, generator=torch.Generator().manual_seed(11))
+
+
+def _uneven(rank, world):
+    """7 samples over 3 ranks (3 + 2 + 2): every rank must take the same number of optimizer steps and of broadcasts."""
+    ctx = D.DPContext.from_env()
+    n, t, h = 7, 4, 6
+    full = _samples(n, t, h)
+    mine = list(D.sample_indices(n, rank, world))
+    block = _StubBlock(h)
+    quant, fp = full[mine].clone(), full[mine].clone()
+    cfg = CalibConfig(epochs=2, nsamples=n, batch_size=1, let=False, lwc=True, deactive_amp=True)
+    res = calibrate_layer(block, quant, fp, None, cfg, dp=ctx)
+    return {"steps": len(res["losses"]), "param": block.upbound_factor.detach().clone(), "quant": quant, "mine": mine}
+
+
+def test_uneven_sample_shards_do_not_deadlock_and_stay_consistent():
+    out = run2(_uneven, world=3)
+    assert [o["steps"] for o in out] == [4, 4, 4]  # 2 epochs x (7 // 3) steps on every rank
+    for o in out[1:]:
+        assert torch.equal(o["param"], out[0]["param"])
+    # the propagation pass visited the samples in global order and every rank kept the outputs of its own samples:
+    # the same outputs as one process running the trained block over all seven samples
+    block = _StubBlock(6)
+    with torch.no_grad():
+        block.upbound_factor.copy_(out[0]["param"])
+    block.set_quant_state(False, True)
+    full = _samples(7, 4, 6)
+    with torch.no_grad():
+        want = torch.stack([block(full[j:j + 1])[0][0] for j in range(7)])
+    for o in out:
+        assert torch.allclose(o["quant"], want[o["mine"]], atol=1e-6)
+
+
+def _too_few(rank, world):
+    ctx = D.DPContext.from_env()
+    full = _samples(4, 4, 6)
+    block = _StubBlock(6)
+    mine = full[:1].clone()  # one sample although the share of 4 samples over 2 ranks is two
+    cfg = CalibConfig(epochs=1, nsamples=4, batch_size=1, let=False, lwc=True, deactive_amp=True)
+    try:
+        calibrate_layer(block, mine, mine.clone(), None, cfg, dp=ctx)
+    except ValueError as e:
+        return str(e)
+    return "no error"
+
+
+def test_a_rank_with_too_few_samples_is_refused_before_any_collective():
+    out = run2(_too_few)
+    assert all("fewer than its share" in o for o in out)
+

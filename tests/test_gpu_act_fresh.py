@@ -140,9 +140,11 @@ def test_llama_shapes_fresh_equals_four_kernel_path(shape, dt, counts, bits):
 
 
 def test_oracle_at_llama_70b_widths():
-    """The oracle itself at C = 8192 and C = 28672 (256 rows keep the CPU side in seconds)."""
-    for C, counts, dt in ((8192, [256] * 32, torch.float32), (28672, [896] * 32, torch.float16), (8192, None, torch.float16)):
-        x = synth.activation((256, C), 77, dt)
+    """The oracle itself at the Llama-2-70B widths C = 8192 and C = 28672, up to the full 2048-token slab."""
+    for R, C, counts, dt in ((256, 8192, [256] * 32, torch.float32), (256, 28672, [896] * 32, torch.float16),
+                             (256, 8192, None, torch.float16), (2048, 8192, [256] * 32, torch.float16),
+                             (2048, 28672, [896] * 32, torch.float32)):
+        x = synth.activation((R, C), 77, dt)
         layout = F.ClusterLayout.get(counts, C, DEV)
         outs, codes, vecs = F.act_fresh_quant_fwd([x.to(DEV)], 8, layout, want_codes=True)
         kw = dict(method="per_cluster" if counts else "per_tensor", metric="ema_minmax", cluster_dim=1 if counts else None,
@@ -150,6 +152,43 @@ def test_oracle_at_llama_70b_widths():
         ref, ref_codes = O.act_forward(x, O.ActState(), 8, "calibration", **kw)
         assert same(outs[0].cpu(), ref)
         assert torch.equal(codes[0].cpu().to(torch.int32), ref_codes.to(torch.int32))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("shape", [(64, 64), (96, 2048)])
+def test_tied_extremes_share_the_scale_gradient_like_autograd(dt, shape):
+    """Three elements tie at the minimum (two of them in one channel) and three at the maximum.  Per-tensor statistics
+    are one reduction over all elements (torch.min / torch.max, quantizer.py:222-223): autograd gives every tied element
+    a third of the scale gradient.  Statistics of an explicit cluster are found per channel first (quantizer.py:190-210):
+    the two tied channels get half each, and the channel with two tied rows splits its half again."""
+    dtype = DT[dt]
+    R, C = shape
+    x = synth.activation(shape, 900, dtype)
+    lo, hi = x.min() - 1, x.max() + 1
+    x[0, 44] = x[0, 61] = x[1, 44] = lo
+    x[5, 3] = x[9, 3] = x[2, 17] = hi
+    g = synth.grad_like(x, 901)
+    xd, gd = x.to(DEV), g.to(DEV)
+    tied = (x == lo) | (x == hi)
+    for counts, kw in ((None, dict(method="per_tensor", metric="minmax")),
+                       ([C], dict(method="per_cluster", metric="minmax", cluster_dim=1, cluster_counts=[C]))):
+        layout = F.ClusterLayout.get(counts, C, DEV)
+        assert layout.flat == (counts is None)
+        xr = x.clone().requires_grad_(True)
+        ref, _ = O.act_forward(xr, O.ActState(), 4, "calibration", **kw)
+        (ref_dx,) = torch.autograd.grad((ref.float() * g.float()).sum(), [xr])
+        outs, _, vecs = F.act_fresh_quant_fwd([xd], 4, layout)
+        assert same(outs[0].cpu(), ref.detach())
+        dx = F.act_fresh_quant_bwd([gd], [xd], vecs, 4, layout)[0].cpu()
+        _, _, o_st, o_dx = _old_path(xd, gd, 4, layout)
+        assert same(dx, o_dx.cpu())
+        got, want = dx[tied].double(), ref_dx[tied].double()
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert ((got - want).abs().max() / want.abs().max()).item() <= tol, (counts, got, want)
+        if counts is None:  # the two ways of splitting really differ on this input
+            layout_h = F.ClusterLayout.get([C], C, DEV)
+            dx_h = F.act_fresh_quant_bwd([gd], [xd], vecs, 4, layout_h)[0].cpu()
+            assert ((dx_h[tied].double() - want).abs().max() / want.abs().max()).item() > 0.05
 
 
 def test_autograd_function_uses_the_fresh_path_and_the_batch_function_agrees():

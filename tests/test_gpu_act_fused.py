@@ -45,7 +45,7 @@ def _phased_bwd(g, x, st, bits, layout):
         L.call("miq_colquant_bwd", L.ptr(g), L.ptr(x), L.ptr(st["scale"]), L.ptr(st["rzp"]), L.ptr(st["chan_min"]),
                L.ptr(st["chan_max"]), L.ptr(st["cmin"]), L.ptr(st["cmax"]), L.ptr(layout.starts), L.i32(layout.n_clusters),
                L.i64(layout.covered), L.ptr(ws), L.i32(nchunk), L.ptr(dx), L.i64(R), L.i64(C), L.i32(bits), L.i32(phase),
-               L.i32(L.dtype_code(x)), L.stream_of(x))
+               L.i32(int(layout.flat)), L.i32(L.dtype_code(x)), L.stream_of(x))
     return dx
 
 

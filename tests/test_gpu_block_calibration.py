@@ -54,7 +54,7 @@ def test_tiny_opt_block_matches_reference_run(fused_softmax):
     indices = reorder_block(q, m["H"], m["F"], m["heads"], enable, m["clusters"], DEV)
     for k, v in indices.items():
         assert torch.equal(v.cpu(), d[f"index_{k}"]), k
-    cfg = CalibConfig(epochs=m["epochs"], nsamples=m["N"], batch_size=1, let=True, lwc=True, deactive_amp=True,
+    cfg = CalibConfig(epochs=m["epochs"], nsamples=m["N"], batch_size=1, let=True, lwc=True, deactive_amp=True, autocast_passes=False,
                       reorder="012345", n_clusters=m["clusters"])
     prefix = "model.decoder.layers.0"
     act_scales = {f"{prefix}.{n}": d[f"act_scale_{n}"] for n in ("self_attn.q_proj", "self_attn.out_proj", "fc1")}
@@ -113,7 +113,7 @@ def test_propagation_with_reference_parameters():
     indices = reorder_block(q, m["H"], m["F"], m["heads"], {f"R{k}": True for k in range(1, 6)}, m["clusters"], DEV)
     R.oc_maxmin_dict.clear()
     R.ic_maxmin_dict.clear()
-    cfg = CalibConfig(epochs=m["epochs"], nsamples=m["N"], batch_size=1, let=True, lwc=True, deactive_amp=True,
+    cfg = CalibConfig(epochs=m["epochs"], nsamples=m["N"], batch_size=1, let=True, lwc=True, deactive_amp=True, autocast_passes=False,
                       reorder="012345", n_clusters=m["clusters"])
     prefix = "model.decoder.layers.0"
     act_scales = {f"{prefix}.{n}": d[f"act_scale_{n}"] for n in ("self_attn.q_proj", "self_attn.out_proj", "fc1")}

@@ -245,6 +245,30 @@ def test_exp2_llama_shapes_vs_oracle(shape, bits):
         assert masked_rel(chain(d_su, su), g[1]) <= 2e-5 and masked_rel(chain(d_sl, sl), g[2]) <= 2e-5
 
 
+@pytest.mark.parametrize("shape,bits,symmetric", [((4096, 4096), 3, True), ((4096, 4096), 4, False), ((2048, 11008), 3, True)])
+def test_exp1_llama_shapes_vs_oracle(shape, bits, symmetric):
+    """The first exponential quantizer (quantize/quantizer_exp.py:92-166) at Llama-2-7B weight shapes, fwd + backward."""
+    x = synth.weight(shape[0], shape[1], 12)
+    up, low = synth.lwc_factors(shape[0], 13)
+    w = synth.grad_like(x, 14)
+    xg = x.clone().requires_grad_(True)
+    pu, pl = up.clone().requires_grad_(True), low.clone().requires_grad_(True)
+    r = O.exp1_row(xg, bits, symmetric, pu, pl)
+    g = torch.autograd.grad((r.out * w).sum(), [xg, pu, pl])
+    su, sl = sig(up, low)
+    out, scale, mid = F.rowquant_exp1_fwd(x.to(DEV), bits, symmetric, su, sl, preactivated=True)
+    assert same(scale.cpu(), r.scale.detach())
+    xs = x
+    if not symmetric:
+        assert same(mid.cpu(), r.rzp.detach())
+        xs = x - r.rzp.detach()
+    nflip = check_exp_forward(xs, r.scale.detach(), out, r.out.detach(), 1)
+    dx, d_su, d_sl = F.rowquant_exp1_bwd(w.to(DEV), x.to(DEV), bits, symmetric, su, sl, preactivated=True)
+    if nflip == 0:
+        assert masked_rel(dx, g[0]) <= 4e-5
+        assert masked_rel(chain(d_su, su), g[1]) <= 2e-5 and masked_rel(chain(d_sl, sl), g[2]) <= 2e-5
+
+
 @pytest.mark.parametrize("shape,hard", [((5120, 5120), False), ((13824, 5120), True), ((1280, 13824), False)])
 def test_mix_llama13b_shapes_vs_oracle(shape, hard):
     """Llama-2-13B weight shapes (the learnable per-output-channel bit-width configuration), soft and hard phase."""
