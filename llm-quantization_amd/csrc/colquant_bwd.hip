@@ -224,8 +224,11 @@ k_colbwd_fold(BwdSlabs slabs, int nchunk, int C) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int j = j0 + 4 * u;
-                v[u] = j < nchunk ? p[(long long)j * C] : 0.f;
+                v[u] = p[(long long)(j < nchunk ? j : nchunk - 1) * C];  // unconditional load, masked below
             }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (j0 + 4 * u >= nchunk) v[u] = 0.f;
             acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
                    (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
         }
@@ -240,7 +243,9 @@ k_colbwd_fold(BwdSlabs slabs, int nchunk, int C) {
 // Every block of a cluster sums the whole cluster (L2-resident vectors, four loads in flight, the same fixed order
 // in every block) and writes the shares of its own slice of channels: a single large cluster (per-tensor
 // statistics) is spread over up to 16 blocks instead of one block walking all channels.
-template <typename T>
+// CHAN: the forward kept per-channel statistics (a channel attains the cluster extreme when its own extreme equals the
+// merged one); otherwise a channel attains it when it holds at least one element equal to the merged extreme.
+template <typename T, bool CHAN>
 __global__ void __launch_bounds__(256)
 k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ starts, int ncl, float qmax, int flat) {
     __shared__ float lds[48];
@@ -252,10 +257,6 @@ k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ start
     const T* __restrict__ kmax = static_cast<const T*>(sb.kmax);
     const float* __restrict__ chan_min = sb.chan_min;
     const float* __restrict__ chan_max = sb.chan_max;
-    // does channel c attain the cluster extreme?  With per-channel statistics: its own extreme equals the merged one;
-    // without: it holds at least one element equal to the merged extreme
-    auto at_max = [&](int c, float mx) { return chan_max ? chan_max[c] == mx : sums[(long long)C + c] > 0.f; };
-    auto at_min = [&](int c, float mn) { return chan_min ? chan_min[c] == mn : sums[2ll * C + c] > 0.f; };
     const int k = blockIdx.x;
     const bool own = k >= ncl;
     const int st = own ? starts[ncl] : starts[k];
@@ -276,48 +277,41 @@ k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ start
     }
     if (en <= st) return;
     const float mn = to_f<T>(kmin[st]), mx = to_f<T>(kmax[st]);  // constant over the cluster
-    // this block's first channel: loaded before the reduction so that its shares need no dependent loads afterwards
-    // (clusters of up to 256 channels per slice are written from registers)
-    const bool has0 = first < en;
-    float n1 = 1.f, n2 = 1.f;
-    bool ax0 = false, an0 = false;
-    if (has0) {
-        n1 = colsum(1, first);
-        n2 = colsum(2, first);
-        ax0 = at_max(first, mx);
-        an0 = at_min(first, mn);
-    }
-    // cluster totals: dS, number of channels attaining the cluster max / min
+    // cluster totals: dS, number of channels (flat: of elements) attaining the cluster max / min.  Every load is
+    // unconditional (an out-of-range channel re-reads the cluster's first one and is masked afterwards): guarded loads
+    // would be issued one by one behind a branch each.
     float acc[3] = {0.f, 0.f, 0.f};
     for (int c = st + threadIdx.x; c < en; c += 1024) {
-        float ds[4];
-        bool ax[4], an[4];
+        float ds[4], n1[4], n2[4], cx[4], cn[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cc = c + 256 * u;
-            const bool in = cc < en;
-            ds[u] = in ? colsum(0, cc) : 0.f;
-            ax[u] = in && at_max(cc, mx);
-            an[u] = in && at_min(cc, mn);
+            const int j = cc < en ? cc : st;
+            ds[u] = colsum(0, j);
+            n1[u] = colsum(1, j);
+            n2[u] = colsum(2, j);
+            if (CHAN) { cx[u] = chan_max[j]; cn[u] = chan_min[j]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            acc[0] += ds[u];
-            acc[1] += ax[u] ? (flat ? colsum(1, c + 256 * u) : 1.f) : 0.f;
-            acc[2] += an[u] ? (flat ? colsum(2, c + 256 * u) : 1.f) : 0.f;
+            const bool in = c + 256 * u < en;
+            const bool ax = in && (CHAN ? cx[u] == mx : n1[u] > 0.f);
+            const bool an = in && (CHAN ? cn[u] == mn : n2[u] > 0.f);
+            acc[0] += in ? ds[u] : 0.f;
+            acc[1] += ax ? (flat ? n1[u] : 1.f) : 0.f;
+            acc[2] += an ? (flat ? n2[u] : 1.f) : 0.f;
         }
     }
     team_sum<256, 3>(acc, lds);
     const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
     const bool live = s_raw >= lo && s_raw <= kClipHi;
     const float d = live ? acc[0] / qmax : 0.f;
-    if (has0) {
-        share_max[first] = ax0 ? (flat ? d / acc[1] : (d / acc[1]) / n1) : 0.f;
-        share_min[first] = an0 ? (flat ? -d / acc[2] : (-d / acc[2]) / n2) : 0.f;
-    }
-    for (int c = first + step; c < en; c += step) {
-        share_max[c] = at_max(c, mx) ? (flat ? d / acc[1] : (d / acc[1]) / colsum(1, c)) : 0.f;
-        share_min[c] = at_min(c, mn) ? (flat ? -d / acc[2] : (-d / acc[2]) / colsum(2, c)) : 0.f;
+    for (int c = first; c < en; c += step) {
+        const float n1 = colsum(1, c), n2 = colsum(2, c);
+        const bool ax = CHAN ? chan_max[c] == mx : n1 > 0.f;
+        const bool an = CHAN ? chan_min[c] == mn : n2 > 0.f;
+        share_max[c] = ax ? (flat ? d / acc[1] : (d / acc[1]) / n1) : 0.f;
+        share_min[c] = an ? (flat ? -d / acc[2] : (-d / acc[2]) / n2) : 0.f;
     }
 }
 
@@ -648,8 +642,12 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
                                starts, qmax, flat);
         } else {
             const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
-            hipLaunchKernelGGL((k_colbwd_shares<T>), dim3(nblk, cluster_slices(C, nblk), n), block, 0, stream, slabs, nchunk, (int)C,
-                               starts, ncl, qmax, flat);
+            if (slabs.s[0].chan_max)
+                hipLaunchKernelGGL((k_colbwd_shares<T, true>), dim3(nblk, cluster_slices(C, nblk), n), block, 0, stream, slabs, nchunk,
+                                   (int)C, starts, ncl, qmax, flat);
+            else
+                hipLaunchKernelGGL((k_colbwd_shares<T, false>), dim3(nblk, cluster_slices(C, nblk), n), block, 0, stream, slabs, nchunk,
+                                   (int)C, starts, ncl, qmax, flat);
         }
         if (vec_ok) hipLaunchKernelGGL((k_colbwd_fixup<T, N>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);
         else hipLaunchKernelGGL((k_colbwd_fixup<T, 1>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);

@@ -22,6 +22,7 @@ from .int_matmul import QuantMatMul
 from .let import (smooth_fc_fc_inplace, smooth_fc_fc_temporary, smooth_ln_fcs_inplace, smooth_ln_fcs_temporary,
                   smooth_q_k_inplace, smooth_q_k_temporary, truncate_number)
 from .omni_norm import OmniLayerNorm, OmniLlamaRMSNorm
+from .quantizer import batched_static_quant, shared_static_quant
 
 TRUNCATE_THRESHOLD = 1e-2  # truncate_number's default where the decoder layers call it (models/transformation.py:18)
 
@@ -231,6 +232,27 @@ class _BlockBase(nn.Module):
                     p.copy_(truncate_number(p))
 
 
+SHARE_ACT_QUANT = True  # module-wide switch (A/B timing): one activation-quantizer evaluation for layers reading one tensor
+
+
+def _linears_on_one_input(linears, x):
+    """[lin(x) for lin in linears] with the input quantized once when the layers' activation quantizers cannot differ."""
+    if SHARE_ACT_QUANT and all(m.use_act_quant and not m.disable_input_quant for m in linears):
+        xq = shared_static_quant([m.act_quantizer for m in linears], x)
+        if xq is not None:
+            return [m(xq, input_quantized=True) for m in linears]
+    return [m(x) for m in linears]
+
+
+def _quant_operands(matmuls_and_slots, xs):
+    """Operand quantizers of the attention matmuls on tensors of one shape (q, k, v), batched into one launch pair when
+    they calibrate on fresh statistics.  matmuls_and_slots: (QuantMatMul, 1 | 2) per tensor."""
+    qs = [(m.x1_quantizer if slot == 1 else m.x2_quantizer) for m, slot in matmuls_and_slots]
+    if SHARE_ACT_QUANT and all(m.use_act_quant for m, _ in matmuls_and_slots):
+        return batched_static_quant(qs, xs)
+    return [(m.quant_x1(x) if slot == 1 else m.quant_x2(x)) for (m, slot), x in zip(matmuls_and_slots, xs)]
+
+
 class _OPTAttention(nn.Module):
     def __init__(self, q, k, v, o, num_heads, args, nbits=None):
         super().__init__()
@@ -255,9 +277,9 @@ class _OPTAttention(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None):
         bsz, tgt_len, _ = hidden_states.size()
-        q = self.qkt_matmul.quant_x1(self.q_proj(hidden_states) * self.scaling)
-        k = self._heads(self.qkt_matmul.quant_x2(self.k_proj(hidden_states)), bsz)
-        v = self._heads(self.pv_matmul.quant_x2(self.v_proj(hidden_states)), bsz)
+        q, k, v = _linears_on_one_input([self.q_proj, self.k_proj, self.v_proj], hidden_states)
+        q, k, v = _quant_operands([(self.qkt_matmul, 1), (self.qkt_matmul, 2), (self.pv_matmul, 2)], [q * self.scaling, k, v])
+        k, v = self._heads(k, bsz), self._heads(v, bsz)
         shape = (bsz * self.num_heads, -1, self.head_dim)
         q = self._heads(q, bsz).view(*shape)
         k = k.view(*shape)
@@ -449,9 +471,10 @@ class _LlamaAttention(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None):
         bsz, q_len, _ = hidden_states.size()
-        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim).transpose(1, 2)
-        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
-        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        q, k, v = _linears_on_one_input([self.q_proj, self.k_proj, self.v_proj], hidden_states)
+        q = q.view(bsz, q_len, self.num_heads, self.head_dim).transpose(1, 2)
+        k = k.view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        v = v.view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
         if position_ids is None:
             position_ids = torch.arange(q_len, device=hidden_states.device).unsqueeze(0)
         q, k = self.rotary_emb(q, k, position_ids)
@@ -460,8 +483,7 @@ class _LlamaAttention(nn.Module):
             k = k.reshape(bsz, self.num_heads, q_len, self.head_dim)
             v = v[:, :, None].expand(bsz, self.num_key_value_heads, self.num_key_value_groups, q_len, self.head_dim)
             v = v.reshape(bsz, self.num_heads, q_len, self.head_dim)
-        q = self.qkt_matmul.quant_x1(q)
-        k = self.qkt_matmul.quant_x2(k)
+        q, k, v = _quant_operands([(self.qkt_matmul, 1), (self.qkt_matmul, 2), (self.pv_matmul, 2)], [q, k, v])
         w = self.qkt_matmul(q, k.transpose(2, 3))
         if self.fused_softmax and F.masked_softmax_supported(w, attention_mask):
             # scale, mask, floor, fp32 softmax and the cast back in one pass over the score matrix
@@ -473,7 +495,6 @@ class _LlamaAttention(nn.Module):
                 w = w.clamp(min=torch.finfo(w.dtype).min)  # torch.max against the constant, without a host-to-device copy
             w = TF.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
         w = self.pv_matmul.quant_x1(w)
-        v = self.pv_matmul.quant_x2(v)
         o = self.pv_matmul(w, v)
         o = o.transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
         return self.o_proj(o)
@@ -490,7 +511,8 @@ class _LlamaMLP(nn.Module):
         self.up_proj = QuantLinear(up, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("up", []), **kw)
 
     def forward(self, x):
-        return self.down_proj(TF.silu(self.gate_proj(x)) * self.up_proj(x))
+        gate, up = _linears_on_one_input([self.gate_proj, self.up_proj], x)
+        return self.down_proj(TF.silu(gate) * up)
 
 
 class QuantLlamaBlock(_BlockBase):

@@ -890,9 +890,16 @@ class ActCalibFQBatch(torch.autograd.Function):
     def forward(ctx, n_bits, layout, holders, *xs):
         C = xs[0].shape[-1]
         x2s = [x.contiguous().reshape(-1, C) for x in xs]
+        k = _tensor_fold(x2s[0].shape[0], C, layout)  # narrow per-tensor slabs as wide rows, as in ActCalibFQ
+        if k > 1:
+            x2s = [x.reshape(-1, C * k) for x in x2s]
+            layout = ClusterLayout.get(None, C * k, xs[0].device)
         outs, _, vecs = act_fresh_quant_fwd(x2s, n_bits, layout)
         for h, v in zip(holders, vecs):
-            h.update(stats_of(v))
+            st = stats_of(v)
+            if k > 1:
+                st = {n: (t if n == "vec" else t[:C]) for n, t in st.items()}
+            h.update(st)
         ctx.layout, ctx.n_bits, ctx.n = layout, n_bits, len(xs)
         ctx.save_for_backward(*x2s, *vecs)
         ctx.set_materialize_grads(False)

@@ -61,7 +61,9 @@ class QuantLinear(nn.Module):
         self.disable_input_quant = disable_input_quant
         self.use_temporary_parameter = False
 
-    def forward(self, input: torch.Tensor):
+    def forward(self, input: torch.Tensor, input_quantized: bool = False):
+        """``input_quantized``: the caller already applied this layer's activation quantizer (one evaluation shared by
+        the layers that read the same tensor, see quantizer.shared_static_quant)."""
         if self.use_temporary_parameter:
             weight = self.temp_weight
             bias = self.temp_bias
@@ -71,7 +73,7 @@ class QuantLinear(nn.Module):
         else:
             weight = self.weight
             bias = self.bias
-        if self.use_act_quant and not self.disable_input_quant:
+        if self.use_act_quant and not self.disable_input_quant and not input_quantized:
             input = self.act_quantizer(input)
         if (self.fused_bias_grad and bias is not None and bias.requires_grad and torch.is_grad_enabled()
                 and self.fwd_func is TF.linear and not self.fwd_kwargs and F.linear_supported(input, weight, bias)):

@@ -263,3 +263,74 @@ class UniformAffineQuantizer(nn.Module):
             self.cached_xmin = fn(self.cached_xmin)
             self.cached_xmax = fn(self.cached_xmax)
         return super()._apply(fn, *a, **k)
+
+
+# ------------------------------------------------------------------------------------------------
+# several static activation quantizers evaluated together
+# ------------------------------------------------------------------------------------------------
+_CONFIG = ("n_bits", "symmetric", "metric", "dynamic", "dynamic_method", "mode", "enable", "cluster_dim")
+
+
+def _same_config(qs):
+    q0 = qs[0]
+    for q in qs[1:]:
+        if type(q) is not UniformAffineQuantizer or any(getattr(q, a) != getattr(q0, a) for a in _CONFIG):
+            return False
+        c0, c1 = q0.cluster_counts, q.cluster_counts
+        if (c0 is None) != (c1 is None) or (c0 is not None and (len(c0) != len(c1) or any(int(a) != int(b) for a, b in zip(c0, c1)))):
+            return False
+        if q.dp is not q0.dp:
+            return False
+    return type(q0) is UniformAffineQuantizer and not q0.dynamic and q0.metric != "fix0to1"
+
+
+def shared_static_quant(quantizers, x):
+    """The result of every quantizer in ``quantizers`` applied to the SAME tensor ``x``, evaluated once when they
+    cannot differ: same configuration and the same state objects (no cached statistics yet, or the ones a previous
+    shared call left in all of them; in eval mode the same scale buffers).  The reference calls three quantizers on one
+    layer-norm output (models/int_llama_layer.py:110-116, models/int_opt_layer.py:175-186) and gets three identical
+    tensors; their backward passes add up to the backward of one (it is linear in the incoming gradient).
+    Returns None when the quantizers have to be called one by one."""
+    q0 = quantizers[0]
+    if len(quantizers) < 2 or not _same_config(quantizers) or q0.n_bits >= 16 or not q0.enable:
+        return None
+    if q0.mode == "calibration":
+        if any(q.cached_xmax is not q0.cached_xmax or q.cached_xmin is not q0.cached_xmin for q in quantizers[1:]):
+            return None
+    else:
+        v0 = q0._vec
+        if v0 is None or any(q._vec is None or q._vec[0] is not v0[0] or q._vec[1] is not v0[1] for q in quantizers[1:]):
+            return None
+    out = q0(x)
+    if q0.mode == "calibration":
+        for q in quantizers[1:]:
+            for name in ("scale", "zero_point", "round_zero_point"):
+                if name not in q._buffers:
+                    if hasattr(q, name):
+                        delattr(q, name)
+                    q.register_buffer(name, q0._buffers[name])
+                else:
+                    q._buffers[name] = q0._buffers[name]
+            d = q.__dict__
+            d["cached_xmin"], d["cached_xmax"], d["_vec"] = q0.cached_xmin, q0.cached_xmax, q0._vec
+    return out
+
+
+def batched_static_quant(quantizers, xs):
+    """[q(x) for q, x in zip(quantizers, xs)] for static quantizers of one configuration on tensors of one shape and
+    dtype, through one pair of kernel launches when every one of them calibrates on fresh statistics (the q / k / v
+    projection outputs of a training step); anything else falls back to one call per quantizer."""
+    q0 = quantizers[0]
+    ok = (len(quantizers) > 1 and _same_config(quantizers) and q0.n_bits < 16 and q0.enable and q0.mode == "calibration"
+          and all(q.cached_xmax is None for q in quantizers) and not (q0.dp is not None and q0.dp.active and q0.dp.sync_stats)
+          and all(x.shape == xs[0].shape and x.dtype == xs[0].dtype and x.is_cuda for x in xs) and xs[0].numel() > 0
+          and not q0.symmetric and q0.dynamic_method in ("per_tensor", "per_cluster"))
+    if not ok:
+        return [q(x) for q, x in zip(quantizers, xs)]
+    layout, kind = q0._layout(xs[0])
+    holders = [{} for _ in quantizers]
+    outs = F.ActCalibFQBatch.apply(q0.n_bits, layout, holders, *xs)
+    for q, x, h in zip(quantizers, xs, holders):
+        q._publish(x, h, kind)
+    return list(outs)
+

@@ -116,6 +116,58 @@ def test_reference_autocast_of_the_fp_and_propagation_passes():
     assert 0 < err <= 5e-3, err  # fp16 GEMMs: different from the fp32 pass, but only by their rounding
 
 
+@pytest.mark.parametrize("kind", ["llama", "opt"])
+def test_shared_and_batched_activation_quantizers_equal_one_call_each(kind):
+    """q / k / v (and gate / up) read one tensor through three identically configured quantizers: evaluating the
+    quantizer once, and quantizing the three projection outputs in one launch pair, must give the same loss to the last
+    bit and the same parameter gradients up to the order in which three gradient contributions are summed."""
+    import miq.blocks as B
+    if kind == "llama":
+        d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+        builder, prefix, sites, is_llama, shifts = build, PREFIX, LET_SITES, True, {}
+    else:
+        import test_gpu_block_calibration as opt
+        d = golden("block")["opt_tiny_w4a4_reorder"]
+        builder, prefix, is_llama = opt.build, "model.decoder.layers.0", False
+        sites = ("self_attn.q_proj", "self_attn.out_proj", "fc1")
+        shifts = {f"{prefix}.{n}": d[f"act_shift_{n}"] for n in sites}
+    m = d["meta"]
+    cfg = config(m)
+    act_scales = {f"{prefix}.{n}": d[f"act_scale_{n}"] for n in sites}
+    x, y = d["inps"][:2].to(DEV), d["fp_out"][:2].to(DEV)
+    mask = d["mask"].to(DEV).repeat(2, 1, 1, 1)
+    res = {}
+    try:
+        for share in (True, False):
+            B.SHARE_ACT_QUANT = share
+            q = builder(d)
+            q.set_quant_state(weight_quant=False, act_quant=True)
+            q.let = True
+            init_let(q, act_scales, shifts, prefix, cfg, None, torch.float32, torch.device(DEV), is_llama=is_llama)
+            with torch.no_grad():
+                q.float()
+            losses = []
+            for _step in range(2):  # the second step runs with freed statistics again, like the training loop
+                q.zero_grad()
+                q.smooth_and_quant_temporary()
+                loss = torch.nn.functional.mse_loss(q(x, attention_mask=mask)[0], y)
+                loss.backward()
+                losses.append(loss.item())
+                for aq in q.act_quantizers():
+                    aq.free()
+            res[share] = (losses, {n: p.grad.clone() for n, p in q.named_parameters() if p.grad is not None},
+                          [aq.scale.clone() for aq in q.act_quantizers() if aq.scale is not None])
+    finally:
+        B.SHARE_ACT_QUANT = True
+    assert res[True][0] == res[False][0]
+    assert len(res[True][2]) == len(res[False][2]) >= 6
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    assert res[True][1].keys() == res[False][1].keys()
+    for n, g in res[True][1].items():
+        assert rel_err(g, res[False][1][n]) <= 2e-5, n
+
+
 def test_llama_propagation_with_reference_parameters():
     """The reference's learned parameters loaded, then only the tail of the layer procedure: quantized
     weights, accumulated per-tensor activation scales and propagated activations must agree closely."""
