@@ -19,8 +19,7 @@ import torch.nn.functional as TF
 from . import functional as F
 from .int_linear import QuantLinear
 from .int_matmul import QuantMatMul
-from .let import (smooth_fc_fc_inplace, smooth_fc_fc_temporary, smooth_ln_fcs_inplace, smooth_ln_fcs_temporary,
-                  smooth_q_k_inplace, smooth_q_k_temporary, truncate_number)
+from .let import LetPlan, LinearStep, NormStep, truncate_number
 from .omni_norm import OmniLayerNorm, OmniLlamaRMSNorm
 from .quantizer import batched_static_quant, shared_static_quant
 
@@ -199,19 +198,46 @@ class _BlockBase(nn.Module):
         return self.fused_let and all(type(m.weight_quantizer) is UniformAffineQuantizer and m.weight_quantizer.let_fusable(m.weight)
                                       for _n, m in self.quant_linears())
 
-    def _let_linear(self, m, cs=None, rs=None, rs_div=True, shift=None):
-        """temp_weight / temp_bias of one linear: quantize((W * cs) / rs or * rs); bias + W @ shift.
-        The caller applies the row factor and the output shift to the bias (small vectors)."""
-        if cs is None and rs is None and shift is None and not self._half_weight_path(m.weight_quantizer, m.weight):
+    def _let_linear(self, st: LinearStep):
+        """temp_weight / temp_bias of one linear of the LET plan with the smoothed weight formed inside the quantizer
+        kernel: quantize((W * col_scale) {/, *} row_scale), and W @ col_shift as a by-product for the bias."""
+        m = st.linear
+        plain = st.col_scale is None and st.row_scale is None and st.col_shift is None
+        if plain and not self._half_weight_path(m.weight_quantizer, m.weight):
             wq, wshift = m.weight_quantizer(m.weight), None  # nothing to fuse: the plain row kernels are leaner
         else:
-            wq, wshift = m.weight_quantizer.forward_let(m.weight, cs, rs, rs_div, shift)
+            wq, wshift = m.weight_quantizer.forward_let(m.weight, st.col_scale, st.row_scale, st.row_div, st.col_shift)
         m.temp_weight = wq
-        if wshift is None:
-            m.temp_bias = m.bias
-        else:
-            m.temp_bias = m.bias + wshift if m.bias is not None else wshift
+        m.temp_bias = st.bias(wshift)
         m.use_temporary_parameter = True
+
+    def _smooth_and_quant_temporary(self):
+        """The training-step form of the block's LET plan followed by the weight quantizers (reference
+        smooth_and_quant_temporary, models/int_opt_layer.py:404-444, models/int_llama_layer.py:279-307)."""
+        if self.let:
+            self._truncate_scales()
+            plan = self.let_plan()
+            if self._let_fusable():
+                plan.set_temporary_norms()
+                for st in plan.linears:
+                    self._let_linear(st)
+                return
+            plan.materialize()
+        else:
+            for _n, m in self.quant_linears():
+                m.temp_weight = m.weight
+        self._quantize_temp_weights()
+
+    @torch.no_grad()
+    def _smooth_and_quant_inplace(self):
+        """The plan committed into the stored weights, then the weights quantized for good (reference
+        smooth_and_quant_inplace)."""
+        if self.let:
+            self._truncate_scales()
+            self.let_plan().commit()
+        for _n, m in self.quant_linears():
+            m.weight = m.weight_quantizer(m.weight)
+            m.use_temporary_parameter = False
 
     def _truncate_scales(self):
         # the smoothing scales are parameters of the block itself (init_let registers them): the list is rebuilt only
@@ -353,58 +379,24 @@ class QuantOPTBlock(_BlockBase):
         h = self.fc2(TF.relu(self.fc1(h)))
         return ((residual + h).view(shape),)
 
-    def _fused_let_temporary(self):
-        """smooth_*_temporary + weight quantization (reference int_opt_layer.py:404-444) with the
-        smoothed weights formed inside the quantizer kernels; biases follow models/transformation.py:24-69."""
+    def let_plan(self) -> LetPlan:
+        """Layer norms hand their scale / shift to q, k, v and to fc1; v_proj -> out_proj; q_proj <-> k_proj
+        (models/int_opt_layer.py:404-427)."""
         a = self.self_attn
         s1, b1, so, bo, sq = (self.qkv_smooth_scale, self.qkv_smooth_shift, self.out_smooth_scale, self.out_smooth_shift,
                               self.qkt_smooth_scale)
-        for ln, sc, sh in ((self.self_attn_layer_norm, s1, b1), (self.final_layer_norm, self.fc1_smooth_scale, self.fc1_smooth_shift)):
-            ln.use_temporary_parameter = True
-            ln.temp_bias = (ln.bias - sh) / sc if getattr(ln, "bias", None) is not None else (-1 * sh) / sc
-            ln.temp_weight = ln.weight / sc
-        self._let_linear(a.q_proj, s1, sq, True, b1)
-        a.q_proj.temp_bias = a.q_proj.temp_bias / sq.view(-1)
-        self._let_linear(a.k_proj, s1, sq, False, b1)
-        a.k_proj.temp_bias = a.k_proj.temp_bias * sq.view(-1)
-        self._let_linear(a.v_proj, s1, so, True, b1)
-        a.v_proj.temp_bias = (a.v_proj.temp_bias - bo) / so.view(-1)
-        self._let_linear(a.out_proj, so, None, True, bo)
-        self._let_linear(self.fc1, self.fc1_smooth_scale, None, True, self.fc1_smooth_shift)
-        self._let_linear(self.fc2)
+        sf, bf = self.fc1_smooth_scale, self.fc1_smooth_shift
+        return LetPlan(
+            norms=[NormStep(self.self_attn_layer_norm, s1, b1), NormStep(self.final_layer_norm, sf, bf)],
+            linears=[LinearStep(a.q_proj, s1, b1, sq, True), LinearStep(a.k_proj, s1, b1, sq, False),
+                     LinearStep(a.v_proj, s1, b1, so, True, bo), LinearStep(a.out_proj, so, bo),
+                     LinearStep(self.fc1, sf, bf), LinearStep(self.fc2)])
 
     def smooth_and_quant_temporary(self):
-        a = self.self_attn
-        if self.let and self._let_fusable():
-            self._truncate_scales()
-            self._fused_let_temporary()
-            return
-        if self.let:
-            self._truncate_scales()
-            smooth_ln_fcs_temporary(self.self_attn_layer_norm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
-                                    self.qkv_smooth_shift)
-            smooth_ln_fcs_temporary(self.final_layer_norm, [self.fc1], self.fc1_smooth_scale, self.fc1_smooth_shift)
-            smooth_fc_fc_temporary(a.v_proj, a.out_proj, self.out_smooth_scale, self.out_smooth_shift)
-            smooth_q_k_temporary(a.q_proj, a.k_proj, self.qkt_smooth_scale)
-            self.fc2.temp_weight = self.fc2.weight
-        else:
-            for _n, m in self.quant_linears():
-                m.temp_weight = m.weight
-        self._quantize_temp_weights()
+        self._smooth_and_quant_temporary()
 
-    @torch.no_grad()
     def smooth_and_quant_inplace(self):
-        a = self.self_attn
-        if self.let:
-            self._truncate_scales()
-            smooth_ln_fcs_inplace(self.self_attn_layer_norm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
-                                  self.qkv_smooth_shift)
-            smooth_ln_fcs_inplace(self.final_layer_norm, [self.fc1], self.fc1_smooth_scale, self.fc1_smooth_shift)
-            smooth_fc_fc_inplace(a.v_proj, a.out_proj, self.out_smooth_scale, self.out_smooth_shift)
-            smooth_q_k_inplace(a.q_proj, a.k_proj, self.qkt_smooth_scale)
-        for _n, m in self.quant_linears():
-            m.weight = m.weight_quantizer(m.weight)
-            m.use_temporary_parameter = False
+        self._smooth_and_quant_inplace()
 
     # names of the linears that receive a LET scale/shift pair, and the reorder index each pair follows
     LET_PAIRS = {"q_proj": ("qkv", "R1"), "out_proj": ("out", "R3"), "fc1": ("fc1", "R4")}
@@ -550,59 +542,21 @@ class QuantLlamaBlock(_BlockBase):
         h = self.mlp(self.post_attention_layernorm(h))
         return (residual + h,)
 
-    def _fused_let_temporary(self):
-        """smooth_*_temporary + weight quantization (reference int_llama_layer.py:279-307) with the
-        smoothed weights formed inside the quantizer kernels."""
+    def let_plan(self) -> LetPlan:
+        """RMSNorms hand their scale / shift to q, k, v and to up / gate; v_proj -> o_proj; q_proj <-> k_proj
+        (models/int_llama_layer.py:279-296)."""
         a, m = self.self_attn, self.mlp
         s1, b1, so, bo, sq = (self.qkv_smooth_scale, self.qkv_smooth_shift, self.out_smooth_scale, self.out_smooth_shift,
                               self.qkt_smooth_scale)
         sf, bf = self.fc1_smooth_scale, self.fc1_smooth_shift
-        for ln, sc, sh in ((self.input_layernorm, s1, b1), (self.post_attention_layernorm, sf, bf)):
-            ln.use_temporary_parameter = True
-            ln.temp_bias = (ln.bias - sh) / sc if getattr(ln, "bias", None) is not None else (-1 * sh) / sc
-            ln.temp_weight = ln.weight / sc
-        self._let_linear(a.q_proj, s1, sq, True, b1)
-        a.q_proj.temp_bias = a.q_proj.temp_bias / sq.view(-1)
-        self._let_linear(a.k_proj, s1, sq, False, b1)
-        a.k_proj.temp_bias = a.k_proj.temp_bias * sq.view(-1)
-        self._let_linear(a.v_proj, s1, so, True, b1)
-        a.v_proj.temp_bias = (a.v_proj.temp_bias - bo) / so.view(-1)
-        self._let_linear(a.o_proj, so, None, True, bo)
-        self._let_linear(m.up_proj, sf, None, True, bf)
-        self._let_linear(m.gate_proj, sf, None, True, bf)
-        self._let_linear(m.down_proj)
+        return LetPlan(
+            norms=[NormStep(self.input_layernorm, s1, b1), NormStep(self.post_attention_layernorm, sf, bf)],
+            linears=[LinearStep(a.q_proj, s1, b1, sq, True), LinearStep(a.k_proj, s1, b1, sq, False),
+                     LinearStep(a.v_proj, s1, b1, so, True, bo), LinearStep(a.o_proj, so, bo),
+                     LinearStep(m.up_proj, sf, bf), LinearStep(m.gate_proj, sf, bf), LinearStep(m.down_proj)])
 
     def smooth_and_quant_temporary(self):
-        a, m = self.self_attn, self.mlp
-        if self.let and self._let_fusable():
-            self._truncate_scales()
-            self._fused_let_temporary()
-            return
-        if self.let:
-            self._truncate_scales()
-            smooth_ln_fcs_temporary(self.input_layernorm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
-                                    self.qkv_smooth_shift)
-            smooth_ln_fcs_temporary(self.post_attention_layernorm, [m.up_proj, m.gate_proj], self.fc1_smooth_scale,
-                                    self.fc1_smooth_shift)
-            smooth_fc_fc_temporary(a.v_proj, a.o_proj, self.out_smooth_scale, self.out_smooth_shift)
-            smooth_q_k_temporary(a.q_proj, a.k_proj, self.qkt_smooth_scale)
-            m.down_proj.temp_weight = m.down_proj.weight
-        else:
-            for _n, mod in self.quant_linears():
-                mod.temp_weight = mod.weight
-        self._quantize_temp_weights()
+        self._smooth_and_quant_temporary()
 
-    @torch.no_grad()
     def smooth_and_quant_inplace(self):
-        a, m = self.self_attn, self.mlp
-        if self.let:
-            self._truncate_scales()
-            smooth_ln_fcs_inplace(self.input_layernorm, [a.q_proj, a.k_proj, a.v_proj], self.qkv_smooth_scale,
-                                  self.qkv_smooth_shift)
-            smooth_ln_fcs_inplace(self.post_attention_layernorm, [m.up_proj, m.gate_proj], self.fc1_smooth_scale,
-                                  self.fc1_smooth_shift)
-            smooth_fc_fc_inplace(a.v_proj, a.o_proj, self.out_smooth_scale, self.out_smooth_shift)
-            smooth_q_k_inplace(a.q_proj, a.k_proj, self.qkt_smooth_scale)
-        for _n, mod in self.quant_linears():
-            mod.weight = mod.weight_quantizer(mod.weight)
-            mod.use_temporary_parameter = False
+        self._smooth_and_quant_inplace()

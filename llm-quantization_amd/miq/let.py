@@ -1,8 +1,26 @@
-"""Learnable equivalent transformations (LET): per-channel scale/shift migrations between a norm
-and the linears that consume it, between v_proj and out_proj, and between q_proj and k_proj.
-Restates models/transformation.py:5-114 of the reference; cheap elementwise torch ops on [C] vectors
-and on the weight matrices (the weight fake-quant kernels then consume the transformed weights)."""
+"""Learnable equivalent transformations (LET) as a migration plan.
+
+A decoder block moves per-channel scales / shifts between neighbouring operators so that activations become easier
+to quantize while the block computes the same function (reference models/transformation.py:24-113, driven from
+models/int_opt_layer.py:404-444 and models/int_llama_layer.py:279-307):
+
+  * a norm hands (x - shift) / scale to the linears that read it, which multiply their input columns by scale and take
+    W @ shift into their bias;
+  * v_proj -> out_proj: v_proj's output rows are shifted and divided, out_proj's input columns take them back;
+  * q_proj <-> k_proj: q rows divided, k rows multiplied by one vector (their product q.k^T is unchanged).
+
+Here a block states these relations ONCE as a LetPlan: per norm its (scale, shift), per linear what happens to its
+input columns and to its output rows.  The same plan is then
+  * materialised into temporary weights / biases that stay functions of the trained vectors (a training step),
+  * committed into the stored weights (after training), or
+  * handed to the LET-fused weight quantizer kernel, which forms (W * col_scale) / row_scale on the fly
+(blocks._BlockBase).  Per element the arithmetic is the reference's, in its order: W * col_scale first, then the row
+factor; bias = ((b + W @ col_shift) - row_shift) {/, *} row_scale.
+"""
 from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
 
 import torch
 
@@ -25,83 +43,102 @@ def truncate_number(number, threshold=1e-2):
     return _Truncate.apply(number, threshold)
 
 
-def _has_bias(m):
-    return hasattr(m, "bias") and m.bias is not None
+@dataclass
+class NormStep:
+    """The norm emits (x - shift) / scale."""
+    norm: torch.nn.Module
+    scale: torch.Tensor
+    shift: torch.Tensor
 
 
-def smooth_ln_fcs_temporary(ln, fcs, scales, shifts):
-    """norm output (x - shift)/scale; consumers absorb W*scale and b + W@shift."""
-    ln.use_temporary_parameter = True
-    fcs = fcs if isinstance(fcs, list) else [fcs]
-    ln.temp_bias = (ln.bias - shifts) / scales if _has_bias(ln) else (-1 * shifts) / scales
-    ln.temp_weight = ln.weight / scales
-    for fc in fcs:
-        fc.use_temporary_parameter = True
-        fc.temp_bias = fc.bias + fc.weight @ shifts if _has_bias(fc) else fc.weight @ shifts
-        fc.temp_weight = fc.weight * scales.view(1, -1)
+@dataclass
+class LinearStep:
+    """What the migrations do to one linear layer y = x W^T + b."""
+    linear: torch.nn.Module
+    col_scale: Optional[torch.Tensor] = None   # input columns multiplied by it (the producer divided by it)
+    col_shift: Optional[torch.Tensor] = None   # the producer subtracted it: b += W @ col_shift
+    row_scale: Optional[torch.Tensor] = None   # output rows divided (row_div) or multiplied by it
+    row_div: bool = True
+    row_shift: Optional[torch.Tensor] = None   # subtracted from the bias before the row factor
+
+    def bias(self, wshift):
+        """The migrated bias, given W @ col_shift (or None); None when there is nothing to add to no bias."""
+        b = self.linear.bias if getattr(self.linear, "bias", None) is not None else None
+        if wshift is not None:
+            b = wshift if b is None else b + wshift
+        if b is None:
+            return None
+        if self.row_shift is not None:
+            b = b - self.row_shift
+        if self.row_scale is not None:
+            r = self.row_scale.view(-1)
+            b = b / r if self.row_div else b * r
+        return b
+
+    def weight(self):
+        w = self.linear.weight
+        if self.col_scale is not None:
+            w = w * self.col_scale.view(1, -1)
+        if self.row_scale is not None:
+            r = self.row_scale.view(-1, 1)
+            w = w / r if self.row_div else w * r
+        return w
+
+    def input_shift_product(self):
+        return self.linear.weight @ self.col_shift if self.col_shift is not None else None
 
 
-def smooth_fc_fc_temporary(fc1, fc2, scales, shifts=None):
-    """fc1 rows are divided by scale (after subtracting shift from its bias), fc2 columns multiplied."""
-    fc1.use_temporary_parameter = True
-    fc2.use_temporary_parameter = True
-    if hasattr(fc1, "temp_weight"):
-        fc1.temp_bias = (fc1.temp_bias - shifts) / scales.view(-1)
-        fc1.temp_weight = fc1.temp_weight / scales.view(-1, 1)
-    else:
-        fc1.temp_bias = fc1.bias / scales.view(-1)
-        fc1.temp_weight = fc1.weight / scales.view(-1, 1)
-    fc2.temp_bias = fc2.bias + fc2.weight @ shifts if _has_bias(fc2) else fc2.weight @ shifts
-    fc2.temp_weight = fc2.weight * scales.view(1, -1)
+def _norm_params(step: NormStep):
+    n = step.norm
+    has_bias = getattr(n, "bias", None) is not None
+    bias = (n.bias - step.shift) / step.scale if has_bias else (-1 * step.shift) / step.scale
+    return n.weight / step.scale, bias
 
 
-def smooth_q_k_temporary(q_proj, k_proj, scales):
-    q_proj.use_temporary_parameter = True
-    k_proj.use_temporary_parameter = True
-    q_proj.temp_weight = q_proj.temp_weight / scales.view(-1, 1)
-    q_proj.temp_bias = q_proj.temp_bias / scales.view(-1)
-    k_proj.temp_weight = k_proj.temp_weight * scales.view(-1, 1)
-    k_proj.temp_bias = k_proj.temp_bias * scales.view(-1)
+@dataclass
+class LetPlan:
+    norms: List[NormStep] = field(default_factory=list)
+    linears: List[LinearStep] = field(default_factory=list)
+
+    def set_temporary_norms(self):
+        for st in self.norms:
+            st.norm.temp_weight, st.norm.temp_bias = _norm_params(st)
+            st.norm.use_temporary_parameter = True
+
+    def materialize(self):
+        """Temporary (differentiable) weights and biases of every operator in the plan; the weights are NOT yet
+        quantized (the caller runs the weight quantizers over ``temp_weight``)."""
+        self.set_temporary_norms()
+        for st in self.linears:
+            m = st.linear
+            m.temp_weight = st.weight()
+            m.temp_bias = st.bias(st.input_shift_product())
+            m.use_temporary_parameter = True
+
+    @torch.no_grad()
+    def commit(self):
+        """Write the migrated weights / biases into the operators themselves (the trained vectors become constants)."""
+        for st in self.norms:
+            w, b = _norm_params(st)
+            _store(st.norm, "weight", w)
+            _store(st.norm, "bias", b)
+            st.norm.use_temporary_parameter = False
+        for st in self.linears:
+            m = st.linear
+            b = st.bias(st.input_shift_product())  # from the stored weight, before it changes
+            w = st.weight()
+            _store(m, "weight", w)
+            if b is not None:
+                _store(m, "bias", b)
+            m.use_temporary_parameter = False
 
 
-def smooth_ln_fcs_inplace(ln, fcs, scales, shifts):
-    ln.use_temporary_parameter = False
-    fcs = fcs if isinstance(fcs, list) else [fcs]
-    if _has_bias(ln):
-        ln.bias.sub_(shifts)
-        ln.bias.div_(scales)
-    else:
-        del ln.bias
-        ln.register_buffer("bias", (-1 * shifts) / scales)
-    ln.weight.div_(scales)
-    for fc in fcs:
-        fc.use_temporary_parameter = False
-        if _has_bias(fc):
-            fc.bias.add_(fc.weight @ shifts)
-        else:
-            del fc.bias
-            fc.register_buffer("bias", fc.weight @ shifts)
-        fc.weight.mul_(scales.view(1, -1))
-
-
-def smooth_fc_fc_inplace(fc1, fc2, scales, shifts=None):
-    fc1.use_temporary_parameter = False
-    fc2.use_temporary_parameter = False
-    fc1.bias.sub_(shifts)
-    fc1.bias.div_(scales.view(-1))
-    fc1.weight.div_(scales.view(-1, 1))
-    if _has_bias(fc2):
-        fc2.bias.add_(fc2.weight @ shifts)
-    else:
-        del fc2.bias
-        fc2.register_buffer("bias", fc2.weight @ shifts)
-    fc2.weight.mul_(scales.view(1, -1))
-
-
-def smooth_q_k_inplace(q_proj, k_proj, scales):
-    q_proj.use_temporary_parameter = False
-    k_proj.use_temporary_parameter = False
-    q_proj.weight.div_(scales.view(-1, 1))
-    q_proj.bias.div_(scales.view(-1))
-    k_proj.weight.mul_(scales.view(-1, 1))
-    k_proj.bias.mul_(scales.view(-1))
+def _store(module, name, value):
+    """module.<name> <- value, in place when a tensor is already there (buffers keep their storage), else as a buffer."""
+    cur = getattr(module, name, None)
+    if isinstance(cur, torch.Tensor) and cur.shape == value.shape:
+        cur.copy_(value)
+        return
+    if hasattr(module, name):
+        delattr(module, name)
+    module.register_buffer(name, value.detach().clone())
