@@ -248,13 +248,27 @@ class UniformAffineQuantizer(nn.Module):
         return F.ActEvalFQ.apply(x, s, z, self.n_bits)
 
     def fake_quant(self, x, scale, round_zero_point):
-        """Quantize-dequantize with given parameters: per-channel ([..., C] / scalar) layouts only."""
+        """Quantize-dequantize with given parameters (reference quantizer.py:99-121).  The layout is read from the
+        SHAPE of ``scale``: one element (per tensor), last axis = channels with every other axis 1 (per channel, what
+        the static calibration leaves in ``self.scale``), or one value per row / per group with a trailing axis of
+        1 (what per_token_dynamic_calibration leaves).  Anything else is refused rather than guessed."""
         C = x.shape[-1]
-        if scale.numel() not in (1, C):
-            raise MiqError("fake_quant with explicit parameters supports scalar or per-last-axis-channel scales")
-        s = scale.to(x.dtype).reshape(-1).expand(C).contiguous()
-        z = round_zero_point.to(x.dtype).reshape(-1).expand(C).contiguous()
-        return F.ActEvalFQ.apply(x, s, z, self.n_bits)
+        if scale.shape != round_zero_point.shape and round_zero_point.numel() != 1:
+            raise MiqError(f"scale {tuple(scale.shape)} and zero point {tuple(round_zero_point.shape)} differ in shape")
+        if scale.numel() == 1 or (scale.shape[-1] == C and scale.numel() == C and C != 1):
+            s = scale.to(x.dtype).reshape(-1).expand(C).contiguous()
+            z = round_zero_point.to(x.dtype).reshape(-1).expand(C).contiguous()
+            return F.ActEvalFQ.apply(x, s, z, self.n_bits)
+        g = int(self.group_size or C)
+        rows = x.numel() // g if g else 0
+        if scale.dim() >= 1 and scale.shape[-1] == 1 and scale.numel() == rows and x.numel() == rows * g:
+            # row-wise parameters: the per-channel kernel on the transposed slab (channels <-> rows)
+            xt = x.reshape(rows, g).t().contiguous()
+            s = scale.to(x.dtype).reshape(-1).contiguous()
+            z = round_zero_point.to(x.dtype).reshape(-1).expand(rows).contiguous()
+            return F.ActEvalFQ.apply(xt, s, z, self.n_bits).t().reshape(x.shape)
+        raise MiqError(f"fake_quant: a scale of shape {tuple(scale.shape)} does not describe a per-tensor, per-channel "
+                       f"([..., {C}]) or per-row ([{rows}, 1]) layout of a tensor of shape {tuple(x.shape)}")
 
     def _apply(self, fn, *a, **k):
         # .half()/.float()/.to(): drop the private kernel-side copies, they are rebuilt lazily

@@ -142,3 +142,28 @@ def test_quant_linear_state_machine():
     assert ql.weight_quantizer.upbound_factor.shape == (32, 1)
     ql.weight_quantizer.register_scales_and_zeros()
     assert "scales" in dict(ql.weight_quantizer.named_buffers())
+
+
+def test_fake_quant_reads_the_layout_from_the_scale_shape():
+    """A [rows, 1] scale on a SQUARE weight (what per_token_dynamic_calibration leaves in ``scale``) is a per-row scale,
+    not a per-column one; per-channel and scalar scales keep working; anything else is refused."""
+    from miq.quantizer import UniformAffineQuantizer
+    from miq._lib import MiqError
+    w = synth.weight(96, 96, 21).to(DEV)
+    q = UniformAffineQuantizer(n_bits=4, per_channel_axes=[0], dynamic=True, dynamic_method="per_channel", lwc=False,
+                               shape=(96, 96)).to(DEV)
+    out = q(w)
+    assert q.scale.shape == (96, 1)
+    again = q.fake_quant(w, q.scale, q.round_zero_point)
+    assert torch.equal(again, out)
+    ref = ((w / q.scale).round() + q.round_zero_point).clamp(0, 15).sub(q.round_zero_point).mul(q.scale)
+    assert torch.equal(again, ref)
+    col_scale = q.scale.reshape(1, 96).contiguous()
+    col = q.fake_quant(w, col_scale, q.round_zero_point.reshape(1, 96).contiguous())
+    ref_col = ((w / col_scale).round() + q.round_zero_point.reshape(1, 96)).clamp(0, 15).sub(q.round_zero_point.reshape(1, 96)).mul(col_scale)
+    assert torch.equal(col, ref_col) and not torch.equal(col, again)
+    one = q.fake_quant(w, q.scale[:1, 0].reshape(()), q.round_zero_point[:1, 0].reshape(()))
+    assert one.shape == w.shape
+    with pytest.raises(MiqError):
+        q.fake_quant(w, q.scale[:48], q.round_zero_point[:48])
+
