@@ -315,13 +315,16 @@ struct SlabPtrs { const void* p[kMaxSlabs]; };
 struct SlabOuts { void* p[kMaxSlabs]; };
 
 // Statistics pass.  Block = 4 waves; lane l owns one 16-byte pack of channels, wave w the rows r0 + w, r0 + w + 4, ...
-// of the block's row chunk with DEPTH rows in flight (every wave-load is one contiguous 1 KiB segment).  blockIdx.z
-// selects the slab; slab i uses the table at ws + 16 + i * ws_stride.
-template <typename T, int VEC, int DEPTH>
+// of the block's row chunk with DEPTH rows in flight (every wave-load is one contiguous 1 KiB segment; rows past the
+// chunk's end are replaced by its last row, which changes no minimum or maximum).  blockIdx.z selects the slab; slab i
+// uses the table at ws + 16 + i * ws_stride.  UNIFORM: every lane's pack lies inside one slot (equal cluster sizes that
+// are multiples of VEC, no channel outside a cluster), so the pack is folded to one pair before the waves meet.
+template <typename T, int VEC, int DEPTH, bool UNIFORM>
 __global__ void __launch_bounds__(256)
 k_colstat_slots(SlabPtrs xs, long long R, int C, int rows_per_chunk, SlotMap sm, u64* ws_base, long long ws_stride, int nrep) {
-    __shared__ float smin[3][64 * VEC];
-    __shared__ float smax[3][64 * VEC];
+    constexpr int NP = UNIFORM ? 1 : VEC;  // pairs a lane hands to wave 0
+    __shared__ float smin[3][64 * NP];
+    __shared__ float smax[3][64 * NP];
     const T* __restrict__ x = static_cast<const T*>(xs.p[blockIdx.z]);
     u64* ws = ws_base;  // the two call counters, shared by all slabs
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -330,16 +333,20 @@ k_colstat_slots(SlabPtrs xs, long long R, int C, int rows_per_chunk, SlotMap sm,
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
+    unsigned tag = 0;
+    if (w == 0) tag = (unsigned)ws[0] + 1u;  // requested ahead of the rows: it has arrived when they have
     float mn[VEC], mx[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { mn[e] = __builtin_inff(); mx[e] = -__builtin_inff(); }
     if (valid) {
         const T* p = x + col0;
-        long long r = r0 + w;
-        for (; r + (DEPTH - 1) * 4 < r1; r += DEPTH * 4) {
+        for (long long r = r0 + w; r < r1; r += DEPTH * 4) {
             Pack<T, VEC> a[DEPTH];
 #pragma unroll
-            for (int u = 0; u < DEPTH; ++u) a[u] = ld_pack<T, VEC>(p + (r + u * 4) * C);
+            for (int u = 0; u < DEPTH; ++u) {
+                const long long ru = r + u * 4;
+                a[u] = ld_pack<T, VEC>(p + (ru < r1 ? ru : r1 - 1) * C);
+            }
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
@@ -349,33 +356,26 @@ k_colstat_slots(SlabPtrs xs, long long R, int C, int rows_per_chunk, SlotMap sm,
                     mx[e] = nmax(mx[e], f);
                 }
         }
-        for (; r < r1; r += 4) {
-            Pack<T, VEC> a = ld_pack<T, VEC>(p + r * C);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float f = to_f<T>(a.e[e]);
-                mn[e] = nmin(mn[e], f);
-                mx[e] = nmax(mx[e], f);
-            }
-        }
     }
-    unsigned tag = 0;
-    if (w == 0) tag = (unsigned)ws[0] + 1u;  // requested before the exchange below, used after it
+    if (UNIFORM) {
+#pragma unroll
+        for (int e = 1; e < VEC; ++e) { mn[0] = nmin(mn[0], mn[e]); mx[0] = nmax(mx[0], mx[e]); }
+    }
     if (w > 0) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            smin[w - 1][lane * VEC + e] = mn[e];
-            smax[w - 1][lane * VEC + e] = mx[e];
+        for (int e = 0; e < NP; ++e) {
+            smin[w - 1][lane * NP + e] = mn[e];
+            smax[w - 1][lane * NP + e] = mx[e];
         }
     }
     __syncthreads();
     if (w != 0) return;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e)
+    for (int e = 0; e < NP; ++e)
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            mn[e] = nmin(mn[e], smin[u][lane * VEC + e]);
-            mx[e] = nmax(mx[e], smax[u][lane * VEC + e]);
+            mn[e] = nmin(mn[e], smin[u][lane * NP + e]);
+            mx[e] = nmax(mx[e], smax[u][lane * NP + e]);
         }
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) ws[1] = tag;
     u64* const table = ws + kSlotStride + blockIdx.z * ws_stride;
@@ -389,15 +389,19 @@ k_colstat_slots(SlabPtrs xs, long long R, int C, int rows_per_chunk, SlotMap sm,
     // A lane whose channels all belong to one slot first joins its neighbours of the same slot (slots are contiguous
     // channel ranges, so equal slots sit in consecutive lanes: a segmented scan); the last lane of every run issues the
     // two atomics.  A lane that straddles slots publishes its channels one by one.
-    int sl[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) sl[e] = valid ? sm(col0 + e) : -1;
+    int sl[NP];
     bool uniform = valid;
+    if (UNIFORM) {
+        sl[0] = valid ? (int)(col0 / sm.csize) : -1;
+    } else {
 #pragma unroll
-    for (int e = 1; e < VEC; ++e) uniform = uniform && (sl[e] == sl[0]);
+        for (int e = 0; e < NP; ++e) sl[e] = valid ? sm(col0 + e) : -1;
+#pragma unroll
+        for (int e = 1; e < NP; ++e) uniform = uniform && (sl[e] == sl[0]);
+    }
     float lo_v = mn[0], hi_v = mx[0];
 #pragma unroll
-    for (int e = 1; e < VEC; ++e) { lo_v = nmin(lo_v, mn[e]); hi_v = nmax(hi_v, mx[e]); }
+    for (int e = 1; e < NP; ++e) { lo_v = nmin(lo_v, mn[e]); hi_v = nmax(hi_v, mx[e]); }
     const int key = uniform ? sl[0] : -2 - lane;  // unique negative key: joins nobody
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -410,7 +414,7 @@ k_colstat_slots(SlabPtrs xs, long long R, int C, int rows_per_chunk, SlotMap sm,
         if (lane == 63 || knext != key) publish(key, lo_v, hi_v);
     } else if (valid) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) publish(sl[e], mn[e], mx[e]);
+        for (int e = 0; e < NP; ++e) publish(sl[e], mn[e], mx[e]);
     }
 }
 
@@ -802,11 +806,14 @@ static int act_fresh_t(int n, const void* const* x, int64_t cluster_size, const 
     const dim3 grid(tiles, nchunk, n);
     u64* ws = static_cast<u64*>(workspace);
     if (vec_ok) {
-        hipLaunchKernelGGL((k_colstat_slots<T, N, 4>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
+        // fp32 keeps 8 rows per lane in flight, fp16 (twice the channels per pack, twice the conversions) 4
+        constexpr int D = sizeof(T) == 4 ? 8 : 4;
+        if (uniform) hipLaunchKernelGGL((k_colstat_slots<T, N, D, true>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
+        else hipLaunchKernelGGL((k_colstat_slots<T, N, D, false>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
         if (nrep == 1) launch_fresh_quant<T, N, 1>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
         else launch_fresh_quant<T, N, kSlotReplicas>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
     } else {
-        hipLaunchKernelGGL((k_colstat_slots<T, 1, 4>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
+        hipLaunchKernelGGL((k_colstat_slots<T, 1, 4, false>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
         if (nrep == 1) launch_fresh_quant<T, 1, 1>(true, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
         else launch_fresh_quant<T, 1, kSlotReplicas>(true, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
     }
