@@ -326,8 +326,8 @@ constexpr int kClusterMax = 1024;
 constexpr int kPairMax = 64;
 template <typename T>
 __global__ void __launch_bounds__(1024)
-k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, const int* __restrict__ starts, float qmax,
-                 int flat) {
+k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, const int* __restrict__ starts, int csize,
+                 float qmax, int flat) {
     __shared__ float part_l[3][4][256];
     __shared__ float tot[3][kClusterMax];
     __shared__ float shr[2][kClusterMax];
@@ -338,10 +338,14 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
     const float* __restrict__ part = sb.ws;
     float* __restrict__ share_min = sb.ws + (3ll * nchunk + 3) * C;
     float* __restrict__ share_max = share_min + C;
-    const int st = starts[blockIdx.x], en = starts[blockIdx.x + 1];
+    // equal clusters: the bounds by arithmetic (the loads below then do not wait for `starts`)
+    const int st = csize > 0 ? (int)blockIdx.x * csize : starts[blockIdx.x];
+    const int en = csize > 0 ? st + csize : starts[blockIdx.x + 1];
     const int W = en - st;
     if (W <= 0) return;
     const int tid = threadIdx.x;
+    // requested now, used after the fold
+    const T kmin_raw = static_cast<const T*>(sb.kmin)[st], kmax_raw = static_cast<const T*>(sb.kmax)[st];
     if (tid == 0) npairs = 0;
     __syncthreads();
     // per-channel fold, TW = blockDim.x / 4 channels at a time: thread (w, c) sums chunks w, w + 4, ... of channel c
@@ -392,7 +396,7 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
         __syncthreads();
     }
     // cluster totals in the order of k_colbwd_shares: 256 strided partial sums, then the tree of team_sum<256, 3>
-    const float mn = to_f<T>(static_cast<const T*>(sb.kmin)[st]), mx = to_f<T>(static_cast<const T*>(sb.kmax)[st]);
+    const float mn = to_f<T>(kmin_raw), mx = to_f<T>(kmax_raw);
     float acc[3] = {0.f, 0.f, 0.f};
     if (tid < 256) {
         for (int c = tid; c < W; c += 1024) {
@@ -440,10 +444,11 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
         if (r1 > R) r1 = R;
         for (long long r = r0 + lane; r < r1; r += 64) {
             const long long at = r * C + st + c;
-            const float xv = to_f<T>(x[at]);
+            const T xr = x[at], dr = dx[at];  // together: one trip to memory instead of two
+            const float xv = to_f<T>(xr);
             const bool hit_x = amx && xv == mx, hit_n = amn && xv == mn;
             if (hit_x || hit_n) {
-                float v = to_f<T>(dx[at]);
+                float v = to_f<T>(dr);
                 if (hit_x) v += hx;
                 if (hit_n) v += hn;
                 dx[at] = from_f<T>(v);
@@ -525,25 +530,21 @@ __device__ __forceinline__ void ld_floats(const float* __restrict__ p, float* ou
 // do any work (their loads are issued eight rows at a time: the kernel is latency-bound); with ReLU-style
 // mass ties every block streams its tile with coalesced 16-byte accesses.
 template <typename T, int VEC>
-__global__ void __launch_bounds__(256)
-k_colbwd_fixup(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, int flagged) {
-    const BwdSlab& sb = slabs.s[blockIdx.z];
-    // behind k_colbwd_cluster: nothing to do unless a cluster with mass ties left its shares here
-    if (flagged && sb.ws[(3ll * nchunk + 5) * C] == 0.f) return;
+__device__ __forceinline__ void fixup_tile(const BwdSlab& sb, int nchunk, long long R, int C, int rows_per_chunk, int tile, int chunk) {
     const T* __restrict__ x = static_cast<const T*>(sb.x);
     const float* __restrict__ part = sb.ws;
     const float* __restrict__ share_min = sb.ws + (3ll * nchunk + 3) * C;
     const float* __restrict__ share_max = share_min + C;
     T* __restrict__ dx = static_cast<T*>(sb.dx);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    const long long col0 = ((long long)tile * 64 + lane) * VEC;
     if (col0 >= C) return;
-    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    const long long r0 = (long long)chunk * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
     float hmn[VEC], hmx[VEC], nmx[VEC], nmn[VEC], cmn[VEC], cmx[VEC];
-    ld_floats<VEC>(part + ((long long)1 * nchunk + blockIdx.y) * C + col0, nmx);
-    ld_floats<VEC>(part + ((long long)2 * nchunk + blockIdx.y) * C + col0, nmn);
+    ld_floats<VEC>(part + ((long long)1 * nchunk + chunk) * C + col0, nmx);
+    ld_floats<VEC>(part + ((long long)2 * nchunk + chunk) * C + col0, nmn);
     ld_floats<VEC>(share_max + col0, hmx);
     ld_floats<VEC>(share_min + col0, hmn);
     if (sb.chan_max) {
@@ -595,6 +596,31 @@ k_colbwd_fixup(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chun
     for (; r < r1; r += 4) fix(ld_pack<T, VEC>(x + r * C + col0), r);
 }
 
+// The correction as a kernel.  flagged == 0: one block per (column tile, row chunk, slab).  flagged != 0 (behind
+// k_colbwd_cluster): a small one-dimensional grid whose blocks first read the flag words of all slabs and leave at
+// once when no cluster with mass ties left its shares (the usual case: the launch costs as little as a launch can);
+// otherwise they walk the (tile, chunk) pairs of the flagged slabs.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_colbwd_fixup(BwdSlabs slabs, int n, int tiles, int nchunk, long long R, int C, int rows_per_chunk, int flagged) {
+    if (!flagged) {
+        fixup_tile<T, VEC>(slabs.s[blockIdx.z], nchunk, R, C, rows_per_chunk, blockIdx.x, blockIdx.y);
+        return;
+    }
+    float f[kMaxBwdSlabs];
+#pragma unroll
+    for (int i = 0; i < kMaxBwdSlabs; ++i) f[i] = slabs.s[i < n ? i : 0].ws[(3ll * nchunk + 5) * C];
+    unsigned live = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxBwdSlabs; ++i) live |= (i < n && f[i] != 0.f) ? (1u << i) : 0u;
+    if (!live) return;
+    const int per_slab = tiles * nchunk;
+    for (int t = blockIdx.x; t < per_slab * n; t += gridDim.x) {
+        const int i = t / per_slab, rem = t - i * per_slab;
+        if (live & (1u << i)) fixup_tile<T, VEC>(slabs.s[i], nchunk, R, C, rows_per_chunk, rem % tiles, rem / tiles);
+    }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Launches the backward over `n` slabs of one shape.  merged: fold + shares + sparse correction in k_colbwd_cluster
@@ -638,8 +664,9 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
             // four chunk sequences x a tile of the cluster's channels (64 .. 256, a multiple of 64) per block
             long long tw = (covered / (ncl > 0 ? ncl : 1) + 63) / 64 * 64;
             tw = tw < 64 ? 64 : (tw > 256 ? 256 : tw);
+            const int csize = (int)(covered / (ncl > 0 ? ncl : 1));  // merged: equal clusters over all channels
             hipLaunchKernelGGL((k_colbwd_cluster<T>), dim3(ncl, 1, n), dim3((unsigned)(4 * tw)), 0, stream, slabs, nchunk, R, (int)C, rpc,
-                               starts, qmax, flat);
+                               starts, csize, qmax, flat);
         } else {
             const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
             if (slabs.s[0].chan_max)
@@ -649,8 +676,10 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
                 hipLaunchKernelGGL((k_colbwd_shares<T, false>), dim3(nblk, cluster_slices(C, nblk), n), block, 0, stream, slabs, nchunk,
                                    (int)C, starts, ncl, qmax, flat);
         }
-        if (vec_ok) hipLaunchKernelGGL((k_colbwd_fixup<T, N>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);
-        else hipLaunchKernelGGL((k_colbwd_fixup<T, 1>), grid, block, 0, stream, slabs, nchunk, R, (int)C, rpc, flagged);
+        const long long pairs = (long long)tiles * nchunk * n;
+        const dim3 fgrid = flagged ? dim3((unsigned)(pairs < 512 ? pairs : 512)) : grid;
+        if (vec_ok) hipLaunchKernelGGL((k_colbwd_fixup<T, N>), fgrid, block, 0, stream, slabs, n, tiles, nchunk, R, (int)C, rpc, flagged);
+        else hipLaunchKernelGGL((k_colbwd_fixup<T, 1>), fgrid, block, 0, stream, slabs, n, tiles, nchunk, R, (int)C, rpc, flagged);
     }
     MIQ_CHECK_LAUNCH(who);
     return 0;
