@@ -25,6 +25,12 @@ in HBM before the timed region.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W]    (N>1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0.
+
+--workload c4 runs the row-sharded weight workload instead: the seven matrices of one Llama-2-13B layer (fp32) through the
+learnable mixed-bit quantizer in its soft and hard phases (forward + backward including d n_bits) and the fixed mixed-bit
+quantizer (forward + backward), every matrix sharded by output channel over the ranks (no collective: rows are
+independent), then one all-gather per matrix of the fixed mixed-bit dequantized shards so that every rank holds the whole
+layer.  The total work is fixed, so this is a strong-scaling measurement.
 """
 from __future__ import annotations
 
@@ -204,6 +210,175 @@ class Workload:
             self.flat.div_(world)
 
 
+L13 = [("q", 5120, 5120), ("k", 5120, 5120), ("v", 5120, 5120), ("o", 5120, 5120), ("gate", 13824, 5120), ("up", 13824, 5120),
+       ("down", 5120, 13824)]
+C4_KERNEL = {"mix_soft_fwd": "k_mix_fwd", "mix_soft_bwd": "k_mix_bwd", "mix_hard_fwd": "k_mix_fwd", "mix_hard_bwd": "k_mix_bwd",
+             "mix2_fwd": "k_uniform_fwd", "mix2_bwd": "k_uniform_bwd", "all_gather": "RCCL all-gather (not a kernel of this library)"}
+
+
+class C4Workload:
+    """Row shards of one Llama-2-13B layer on this rank.  Every rank draws the same full matrices (same seed), keeps
+    its rows (miq.dist.shard_weight_rows) and drops the rest."""
+
+    def __init__(self, dev, ctx, rehearsal):
+        from miq.dist import shard_weight_rows
+        self.dev, self.ctx, self.rehearsal = dev, ctx, rehearsal
+        self.rows_total = [o for _n, o, _c in L13]
+        self.w, self.g, self.up, self.low, self.bits, self.fixed = [], [], [], [], [], []
+        gen = torch.Generator(device=dev)
+        for i, (_n, o, c) in enumerate(L13):
+            gen.manual_seed(1300 + i)
+            full = torch.randn(o, c, device=dev, generator=gen) * 0.02
+            (sl, shard), = shard_weight_rows([full], ctx)
+            self.w.append(shard.clone())
+            del full
+            rows = self.w[-1].shape[0]
+            self.g.append(torch.randn(rows, c, device=dev, generator=gen) * 1e-3)
+            u, l = synth.lwc_factors(o, 1400 + i)
+            self.up.append(u[sl].contiguous().to(dev))
+            self.low.append(l[sl].contiguous().to(dev))
+            self.bits.append(synth.mix_bits(o, 3.0, 1500 + i)[sl].contiguous().to(dev))
+            self.fixed.append(synth.mix2_bits(o, 1600 + i)[sl].contiguous().to(dev))
+        self.full = [torch.empty(o, c, device=dev) for _n, o, c in L13] if ctx.active else None
+        self.deq = [None] * len(L13)
+
+    def bytes(self):
+        """Algorithmic bytes of the WHOLE layer per step (the shards of all ranks together)."""
+        n = sum(o * c * 4 for _n, o, c in L13)
+        by = {"mix_soft_fwd": 2 * n, "mix_soft_bwd": 3 * n, "mix_hard_fwd": 2 * n, "mix_hard_bwd": 3 * n, "mix2_fwd": 2 * n,
+              "mix2_bwd": 3 * n}
+        return by
+
+    def gather_bytes_in(self):
+        """Bytes that arrive at every rank in the all-gather of one step."""
+        w = self.ctx.world
+        return sum(o * c * 4 for _n, o, c in L13) * (w - 1) // w
+
+    def families(self):
+        ids = range(len(L13))
+
+        def mix(hard, bwd):
+            def run():
+                for i in ids:
+                    if bwd:
+                        F.rowquant_mix_bwd(self.g[i], self.w[i], self.bits[i], False, self.up[i], self.low[i], hard=hard, want_dx=True)
+                    else:
+                        F.rowquant_mix_fwd(self.w[i], self.bits[i], False, self.up[i], self.low[i], hard=hard)
+            return run
+
+        def mix2_fwd():
+            for i in ids:
+                self.deq[i] = F.rowquant_uniform_fwd(self.w[i], 4, False, self.up[i], self.low[i], 0, self.fixed[i], True)[0]
+
+        def mix2_bwd():
+            for i in ids:
+                F.rowquant_uniform_bwd(self.g[i], self.w[i], 4, False, self.up[i], self.low[i], 0, self.fixed[i], True, want_dx=True)
+
+        return [("mix_soft_fwd", mix(False, False)), ("mix_soft_bwd", mix(False, True)), ("mix_hard_fwd", mix(True, False)),
+                ("mix_hard_bwd", mix(True, True)), ("mix2_fwd", mix2_fwd), ("mix2_bwd", mix2_bwd)]
+
+    def capture(self):
+        fams = self.families()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for _n, fn in fams:
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        out = []
+        for name, fn in fams:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            out.append((name, g.replay))
+        return out
+
+    def all_gather(self):
+        from miq.dist import gather_row_shards
+        for i, rows in enumerate(self.rows_total):
+            if self.rehearsal:  # gloo moves host copies
+                host = gather_row_shards(self.deq[i].cpu(), rows, self.ctx)
+                self.full[i].copy_(host)
+            else:
+                gather_row_shards(self.deq[i], rows, self.ctx, out=self.full[i])
+
+    def step(self, fams, seg, timed):
+        for name, fn in fams:
+            seg.run(name, fn, timed)
+        if self.ctx.active:
+            seg.run("all_gather", self.all_gather, timed)
+
+
+def run_c4(args, world, rank, dev, rehearsal, barrier):
+    from miq.dist import DPContext
+    ctx = DPContext.from_env()
+    wl = C4Workload(dev, ctx, rehearsal)
+    seg = Segments()
+    fams = wl.families() if args.eager else wl.capture()
+    for _ in range(args.warmup):
+        wl.step(fams, seg, False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(fams, seg, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    totals = seg.totals_ms()
+    by = wl.bytes()
+    step_bytes = sum(by.values())
+    # rank 0's own kernels move 1/world of the layer: per-rank GB/s against this GPU's HBM peak
+    fam = {k: {"kernel": C4_KERNEL[k], "GBps_per_rank": round(by[k] / world * args.steps / (totals[k] * 1e-3) / 1e9, 1),
+               "frac_hbm_peak": round(by[k] / world * args.steps / (totals[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": len(L13)} for k in by}
+    if world > 1:
+        ms = totals["all_gather"] / args.steps
+        fam["all_gather"] = {"kernel": C4_KERNEL["all_gather"], "ms_per_step": round(ms, 4),
+                             "GBps_into_each_rank": round(wl.gather_bytes_in() / (ms * 1e-3) / 1e9, 1),
+                             "collectives_per_step": len(L13),
+                             "transport": "gloo over host copies (one-GPU rehearsal)" if rehearsal else "RCCL over xGMI"}
+    dom = max(by, key=lambda k: totals[k])
+    achieved = by[dom] / world * args.steps / (totals[dom] * 1e-3) / 1e9
+    out = {
+        "metric": "fake-quant GB/s (% HBM peak) + OmniQuant block-calib s/layer, Llama-2-7B",
+        "value": round(step_bytes * args.steps / dt / 1e9, 1),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "Llama-2-13B layer, mixed-bit weights with per-output-channel learnable bits: learnable mixed-bit "
+                               "soft + hard phases fwd+bwd (incl. d n_bits) and fixed mixed-bit (10/80/10 % of 4/3/2 bit) fwd+bwd "
+                               "on the 7 matrices (fp32), rows sharded over the ranks"
+                               + (", all-gather of the fixed mixed-bit dequantized shards (inside the timed region)" if world > 1 else ""),
+                   "rows_per_rank": [wl.w[i].shape[0] for i in range(len(L13))],
+                   "launch": "eager" if args.eager else "hipGraph replay per kernel family",
+                   "parallelism": f"row shards x{world}" + (" + all-gather" if world > 1 else ""),
+                   "note": "value = bytes of the whole layer / wall time of the slowest rank, all-gather included; no hardware "
+                           "scaling curve exists for this workload until it is run on a multi-GPU node"},
+        "frac_hbm_peak": round(step_bytes / world * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm", "kernel": C4_KERNEL[dom], "family": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                     "bytes_per_launch": by[dom] // world // len(L13),
+                     "avg_launch_us": round(totals[dom] * 1e3 / (len(L13) * args.steps), 2)},
+        "families": fam,
+    }
+    print(json.dumps(out))
+
+
 def cpu_baseline(threads: int):
     """The CPU oracle (bit-checked against the reference's golden vectors) on a bounded sample of the
     same workload: one [4096,4096] weight forward+backward and one [1,2048,4096] fp32 activation site
@@ -281,6 +456,9 @@ def main():
                     help="with N > 1 ranks: also time the data-parallel block calibration (off by default there: a rank "
                          "that fails inside it would leave the others waiting in a collective before the result line)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
+    ap.add_argument("--workload", choices=("c2", "c4"), default="c2",
+                    help="c2 (default): the Llama-2-7B W4A4 calibration-step workload the metric is quoted on; c4: Llama-2-13B "
+                         "mixed-bit weight quantization with the rows sharded over the ranks")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -304,14 +482,20 @@ def main():
         else:
             torch.distributed.init_process_group("nccl", device_id=torch.device(dev))
 
-    wl = Workload(dev, seed=2 + 1000 * rank)
-    seg = Segments()
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if args.workload == "c4":
+        run_c4(args, world, rank, dev, rehearsal, barrier)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    wl = Workload(dev, seed=2 + 1000 * rank)
+    seg = Segments()
 
     fams = wl.families() if args.eager else wl.capture()
     for _ in range(args.warmup):

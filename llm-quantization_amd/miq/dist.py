@@ -126,3 +126,49 @@ def shard_weight_rows(weights: List[torch.Tensor], ctx: DPContext):
         a, b = shard_range(w.shape[0], ctx.rank, ctx.world)
         out.append((slice(a, b), w[a:b]))
     return out
+
+
+def gather_row_shards(shard: torch.Tensor, rows_total: int, ctx: DPContext, out: Optional[torch.Tensor] = None):
+    """Reassemble an [O, I] matrix on every rank from the ranks' row shards (the ranges of shard_range, in rank order).
+
+    Equal shards are gathered straight into the result (its memory IS the concatenation of the shards: one collective,
+    no copy); otherwise every rank pads its shard to the largest one, one collective fills a [world * max_rows, I]
+    staging tensor and the valid rows are copied out.  Point-to-point xGMI links carry O * I * (world - 1) / world
+    elements into every rank either way."""
+    cols = shard.shape[1:]
+    if out is None:
+        out = torch.empty((rows_total, *cols), dtype=shard.dtype, device=shard.device)
+    if not ctx.active:
+        out.copy_(shard)
+        return out
+    a, b = shard_range(rows_total, ctx.rank, ctx.world)
+    if shard.shape[0] != b - a:
+        raise ValueError(f"rank {ctx.rank} holds {shard.shape[0]} rows, its range [{a}, {b}) has {b - a}")
+    if rows_total % ctx.world == 0:
+        dist.all_gather_into_tensor(out, shard.contiguous(), group=ctx.group)
+        return out
+    most = -(-rows_total // ctx.world)
+    padded = torch.zeros((most, *cols), dtype=shard.dtype, device=shard.device)
+    padded[:b - a].copy_(shard)
+    stage = torch.empty((ctx.world * most, *cols), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(stage, padded, group=ctx.group)
+    stage = stage.view(ctx.world, most, *cols)
+    for r in range(ctx.world):
+        ra, rb = shard_range(rows_total, r, ctx.world)
+        out[ra:rb].copy_(stage[r, :rb - ra])
+    return out
+
+
+def quantize_rows_sharded(weights: List[torch.Tensor], ctx: DPContext, quantize, gather: bool = True):
+    """The for-all-layers weight quantization sharded by output channel: ``quantize(row_shard)`` runs on this rank's
+    rows of every [O, I] matrix (row-wise quantizers need nothing from other rows), and with ``gather`` every rank gets
+    the full dequantized matrices back.  Returns the list of full matrices (gather) or of (row slice, shard) pairs."""
+    out = []
+    for sl, w in shard_weight_rows(weights, ctx):
+        q = quantize(w)
+        if gather:
+            out.append(gather_row_shards(q, weights[len(out)].shape[0], ctx))
+        else:
+            out.append((sl, q))
+    return out
+

@@ -261,3 +261,37 @@ def test_a_rank_with_too_few_samples_is_refused_before_any_collective():
     out = run2(_too_few)
     assert all("fewer than its share" in o for o in out)
 
+
+
+def _stub_quantize(w):
+    """A row-wise stand-in for the weight quantizers (4-bit min/max grid per row), plain torch so that it runs on CPU."""
+    mn, mx = w.amin(1, keepdim=True), w.amax(1, keepdim=True)
+    s = ((mx - mn) / 15).clamp(1e-5, 1e4)
+    z = (-mn / s).round()
+    return ((w / s).round() + z).clamp(0, 15).sub(z).mul(s)
+
+
+def _sharded_quant(rank, world):
+    ctx = D.DPContext.from_env()
+    g = torch.Generator().manual_seed(11)
+    weights = [torch.randn(o, i, generator=g) for o, i in ((8, 5), (7, 3), (12, 4), (2, 6))]  # even and uneven row counts
+    full = D.quantize_rows_sharded(weights, ctx, _stub_quantize, gather=True)
+    parts = D.quantize_rows_sharded(weights, ctx, _stub_quantize, gather=False)
+    rows = [(sl.start, sl.stop) for sl, _q in parts]
+    return [f.clone() for f in full], rows
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_quantization_reassembles_the_full_matrices(world):
+    """shard by output channel -> quantize the shard -> all-gather == quantizing the whole matrix (rows are independent);
+    row counts that do not divide by the world size go through the padded gather."""
+    res = run2(_sharded_quant, world)
+    g = torch.Generator().manual_seed(11)
+    weights = [torch.randn(o, i, generator=g) for o, i in ((8, 5), (7, 3), (12, 4), (2, 6))]
+    want = [_stub_quantize(w) for w in weights]
+    for r in range(world):
+        full, rows = res[r]
+        for f, w in zip(full, want):
+            assert torch.equal(f, w)
+        for (a, b), w in zip(rows, weights):
+            assert (a, b) == D.shard_range(w.shape[0], r, world)
