@@ -10,7 +10,7 @@ One "step" = everything the quantizer kernels do for ONE calibration sample of 2
             2 reorder gathers of the residual stream (fp16, [1,2048,4096])
             10 activation sites: per-cluster EMA min/max calibration + A4 quantization; sites whose inputs exist side
             by side in a decoder block go through one call (the three q/k/v inputs, the three q/k/v projection
-            outputs, the gate/up inputs: 5 calls of 2 launches for the 10 sites; backward 5 calls of 3 launches)
+            outputs, the gate/up inputs: 5 calls of 2 launches for the 10 sites, forward and backward)
               q/k/v inputs   3 x [1,2048,4096] fp32 (layer-norm output), 32 clusters x 128 channels
               q, k, v, o-in  4 x [1,2048,4096] fp16, 128 clusters x 32 channels (4 per head)
               gate/up inputs 2 x [2048,4096]   fp32, 32 clusters x 128
@@ -68,7 +68,7 @@ W_BITS, A_BITS = 4, 4
 SITE_GROUPS = [[0, 1, 2], [3, 4, 5], [6], [7, 8], [9]]
 # the rocprofv3 kernel behind every family (the activation families are chains; their streaming kernel is named)
 FAMILY_KERNEL = {"rowquant_fwd": "k_uniform_fwd_batch", "rowquant_bwd": "k_uniform_bwd_batch",
-                 "act_calib_quant_fwd": "k_colstat_slots + k_colquant_slots", "act_bwd": "k_colbwd_stream (+ k_colbwd_cluster, k_colbwd_fixup)",
+                 "act_calib_quant_fwd": "k_colstat_slots + k_colquant_slots", "act_bwd": "k_colbwd_stream (+ k_colbwd_cluster)",
                  "gather_fwd": "k_gather", "gather_bwd": "k_gather"}
 
 
@@ -126,7 +126,7 @@ class Workload:
     def launches(self):
         n_w = len({c for _n, _o, c in WEIGHTS})  # one launch per row width
         return {"rowquant_fwd": n_w, "rowquant_bwd": n_w, "act_calib_quant_fwd": 2 * len(SITE_GROUPS),
-                "act_bwd": 3 * len(SITE_GROUPS), "gather_fwd": 2, "gather_bwd": 2}
+                "act_bwd": 2 * len(SITE_GROUPS), "gather_fwd": 2, "gather_bwd": 2}
 
     def families(self):
         """Ordered (name, callable) pairs; every callable only enqueues kernels on the current stream."""

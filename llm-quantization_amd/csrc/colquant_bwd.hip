@@ -321,13 +321,15 @@ k_colbwd_shares(BwdSlabs slabs, int nchunk, int C, const int* __restrict__ start
 // k_colbwd_shares), so the shares carry the same bits.  While folding the tie counts the block notes which (row chunk,
 // channel) pairs hold an element at a cluster extreme; up to kPairMax of them are corrected right here (one wave scans
 // the pair's rows), and the shares it publishes for k_colbwd_fixup are then zero.  A cluster with more pairs (ReLU-style
-// mass ties) publishes its shares and raises the slab's flag, and k_colbwd_fixup streams over it.
+// mass ties) either walks its whole slab right here (inline_mass: the host chose it because the slab is small; no
+// correction launch follows) or publishes its shares and raises the slab's flag, and k_colbwd_fixup streams over it.
 constexpr int kClusterMax = 1024;
 constexpr int kPairMax = 64;
+constexpr long long kInlineMass = 1ll << 20;  // elements of a cluster slab one block corrects itself under mass ties
 template <typename T>
 __global__ void __launch_bounds__(1024)
 k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, const int* __restrict__ starts, int csize,
-                 float qmax, int flat) {
+                 float qmax, int flat, int inline_mass) {
     __shared__ float part_l[3][4][256];
     __shared__ float tot[3][kClusterMax];
     __shared__ float shr[2][kClusterMax];
@@ -416,22 +418,55 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
     const bool live = s_raw >= lo && s_raw <= kClipHi;
     const float d = live ? acc[0] / qmax : 0.f;
     const bool mass = npairs > kPairMax;
+    const bool publish = mass && !inline_mass;
     for (int c = tid; c < W; c += blockDim.x) {
         const float hx = tot[1][c] > 0.f ? (flat ? d / acc[1] : (d / acc[1]) / tot[1][c]) : 0.f;
         const float hn = tot[2][c] > 0.f ? (flat ? -d / acc[2] : (-d / acc[2]) / tot[2][c]) : 0.f;
         shr[0][c] = hx;
         shr[1][c] = hn;
-        share_max[st + c] = mass ? hx : 0.f;
-        share_min[st + c] = mass ? hn : 0.f;
+        if (!inline_mass) {
+            share_max[st + c] = publish ? hx : 0.f;
+            share_min[st + c] = publish ? hn : 0.f;
+        }
     }
-    if (mass) {
+    if (publish) {
         if (tid == 0) sb.ws[(3ll * nchunk + 5) * C] = 1.f;
         return;
     }
     __syncthreads();
-    // sparse correction: wave v takes pairs v, v + nwaves, ...; its lanes scan the rows of the pair's chunk
     const T* __restrict__ x = static_cast<const T*>(sb.x);
     T* __restrict__ dx = static_cast<T*>(sb.dx);
+    if (mass) {
+        // mass ties in a cluster slab small enough for one block: walk all of its elements, eight rows in flight per
+        // thread, consecutive threads on consecutive channels.  (direct + share_max) + share_min as everywhere.
+        const long long total = R * W;
+        const long long step = blockDim.x;
+        for (long long i0 = tid; i0 < total; i0 += 8 * step) {
+            T xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long i = i0 + u * step < total ? i0 + u * step : i0;
+                xv[u] = x[(i / W) * C + st + (int)(i % W)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long i = i0 + u * step;
+                if (i >= total) break;
+                const int c = (int)(i % W);
+                const float xf = to_f<T>(xv[u]), hx = shr[0][c], hn = shr[1][c];
+                const bool hit_x = hx != 0.f && xf == mx, hit_n = hn != 0.f && xf == mn;
+                if (hit_x || hit_n) {
+                    const long long at = (i / W) * C + st + c;
+                    float v = to_f<T>(dx[at]);
+                    if (hit_x) v += hx;
+                    if (hit_n) v += hn;
+                    dx[at] = from_f<T>(v);
+                }
+            }
+        }
+        return;
+    }
+    // sparse correction: wave v takes pairs v, v + nwaves, ...; its lanes scan the rows of the pair's chunk
     const int lane = tid & 63;
     for (int i = tid >> 6; i < npairs; i += nwaves) {
         const int e = pairs[i];
@@ -651,7 +686,10 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
         MIQ_CHECK_LAUNCH(who);
         return 0;
     }
-    const int flagged = merged ? 1 : 0;
+    // a cluster slab of up to kInlineMass elements is corrected by its own block of k_colbwd_cluster even under mass ties:
+    // no flag and no correction launch then
+    const bool inline_mass = merged && R * (covered / (ncl > 0 ? ncl : 1)) <= kInlineMass;
+    const int flagged = merged && !inline_mass ? 1 : 0;
     if (phase != 2) {
         if (vec_ok && uniform) hipLaunchKernelGGL((k_colbwd_stream<T, N, true>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
         else if (vec_ok) hipLaunchKernelGGL((k_colbwd_stream<T, N, false>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
@@ -666,7 +704,11 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
             tw = tw < 64 ? 64 : (tw > 256 ? 256 : tw);
             const int csize = (int)(covered / (ncl > 0 ? ncl : 1));  // merged: equal clusters over all channels
             hipLaunchKernelGGL((k_colbwd_cluster<T>), dim3(ncl, 1, n), dim3((unsigned)(4 * tw)), 0, stream, slabs, nchunk, R, (int)C, rpc,
-                               starts, csize, qmax, flat);
+                               starts, csize, qmax, flat, inline_mass ? 1 : 0);
+            if (inline_mass) {
+                MIQ_CHECK_LAUNCH(who);
+                return 0;
+            }
         } else {
             const unsigned nblk = (unsigned)(ncl + (covered < C ? 1 : 0));
             if (slabs.s[0].chan_max)

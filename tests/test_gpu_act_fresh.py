@@ -35,6 +35,7 @@ CASES = [
     ((2100, 2048), "f16", 4, None),                           # one cluster wider than the merged backward handles
     ((64, 100), "f16", 5, [5] * 20),                          # C not a multiple of the 8-element pack
     ((40, 1200), "f32", 4, [1200]),                           # one cluster of more than 1024 channels
+    ((2100, 1024), "f16", 4, [512] * 2),                      # cluster slabs too large for the in-block mass-tie correction
 ]
 
 
