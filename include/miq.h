@@ -184,8 +184,9 @@ int miq_act_calib_quant_fwd(const void* x, const void* cached_min, const void* c
  *                 Calls that share a workspace must be ordered on one stream.
  * Backward (what autograd derives, as miq_colquant_bwd): stats = the [5, C] blocks of the forward; the extreme elements
  * are found by comparing with the merged statistics.  With equal clusters of at most 1024 channels that cover every
- * channel the chunk fold, the shares and the (usually sparse) correction run in one launch (3 launches in all, the
- * last one a no-op unless a cluster has mass ties), otherwise in the four of miq_colquant_bwd; same bits either way.
+ * channel the chunk fold, the shares and the (usually sparse) correction run in one launch: 2 launches in all when a
+ * cluster's slab R * cluster_size has at most 2^20 elements (its block then also handles mass ties), else 3, the last
+ * one a no-op unless a cluster has mass ties; otherwise the four launches of miq_colquant_bwd; same bits either way.
  *   starts        [n_clusters + 1] int32 prefix sums of the cluster sizes on the device
  *   flat_ties     as for miq_colquant_bwd
  *   workspace     miq_act_fresh_bwd_workspace(n, R, C, dtype) BYTES, 16-byte aligned, no initialisation needed
@@ -237,6 +238,42 @@ int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int6
 int miq_gather_layernorm_fwd(const void* x, const int* idx, const void* weight, const void* bias, void* out,
                              float* mean_out, float* rstd_out, int64_t R, int64_t C, float eps, int x_dtype,
                              int w_dtype, int out_dtype, void* stream);
+
+/*
+ * The norm in front of a static activation quantizer that calibrates on fresh statistics (the layer norms feeding the
+ * q/k/v and fc1 / gate / up projections: quantize/omni_norm.py:29-42,60-71 followed by
+ * UniformAffineQuantizer.forward in calibration mode, quantize/quantizer.py:124-142,170-214), without the statistics
+ * pass over the norm's output:
+ *   miq_gather_layernorm_fwd_stats / miq_rmsnorm_fwd_stats   the norm as above; every row additionally folds the minima
+ *       and maxima of the values it STORES (after rounding to the output dtype) into the statistics table that
+ *       miq_act_fresh_quant_fwd keeps in `stat_workspace` (slab 0), i.e. exactly what that function's statistics kernel
+ *       would compute from `out`;
+ *   miq_act_quant_from_table   the quantize half of miq_act_fresh_quant_fwd for one slab whose statistics are already
+ *       in the table: out / codes_out / stats_out as there.
+ * The two calls must follow each other on one stream with nothing else using the workspace in between.  Cluster
+ * layout arguments (cluster_size, slot_of, n_clusters, covered) as for miq_act_fresh_quant_fwd (one cluster of C
+ * channels = per-tensor statistics); stat_workspace: miq_act_fresh_workspace(1, C, n_clusters, covered) bytes, as there.
+ *
+ * miq_gather_layernorm_bwd: backward of miq_gather_layernorm_fwd (autograd of index_select + layer_norm) from the saved
+ * mean / rstd.  With xg[c] = x[idx[c]], u = (xg - mean) * rstd, gw = grad_out * weight:
+ *   dx[r, idx[c]] = rstd * (gw - mean_c(gw) - u * mean_c(gw * u));  d_weight[c] = sum_r grad_out * u;  d_bias[c] = sum_r grad_out
+ * grad_out: [R, C] of g_dtype; dx: [R, C] of x_dtype; d_weight, d_bias: fp32 [C]; each of dx / d_weight / d_bias may be
+ * NULL.  workspace: miq_gather_layernorm_bwd_workspace(R, C) floats, needed for d_weight / d_bias.
+ */
+int miq_gather_layernorm_fwd_stats(const void* x, const int* idx, const void* weight, const void* bias, void* out,
+                                   float* mean_out, float* rstd_out, int64_t R, int64_t C, float eps, int x_dtype,
+                                   int w_dtype, int out_dtype, int64_t cluster_size, const int* slot_of, int n_clusters,
+                                   int64_t covered, void* stat_workspace, void* stream);
+int miq_rmsnorm_fwd_stats(const void* x, const float* weight, const float* bias, void* out, float* rstd_out, int64_t R,
+                          int64_t C, float eps, int dtype, int64_t cluster_size, const int* slot_of, int n_clusters,
+                          int64_t covered, void* stat_workspace, void* stream);
+int miq_act_quant_from_table(const void* x, int64_t cluster_size, const int* slot_of, int n_clusters, int64_t covered,
+                             int n_bits, void* workspace, void* out, void* codes_out, void* stats_out, int64_t R, int64_t C,
+                             int dtype, void* stream);
+int64_t miq_gather_layernorm_bwd_workspace(int64_t R, int64_t C);
+int miq_gather_layernorm_bwd(const void* grad_out, const void* x, const int* idx, const void* weight, const float* mean,
+                             const float* rstd, void* dx, float* d_weight, float* d_bias, float* workspace, int64_t R,
+                             int64_t C, int x_dtype, int w_dtype, int g_dtype, void* stream);
 
 /*
  * Exponential/log weight quantizer v2 (levels 0, +-1, +-2, ..., +-2^(2^(n-1)-2)), n_bits in [2, 4].

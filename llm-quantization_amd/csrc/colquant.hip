@@ -12,6 +12,7 @@
 #include <mutex>
 #include <type_traits>
 #include "miq_common.h"
+#include "slot_table.h"
 
 namespace miq {
 
@@ -278,42 +279,6 @@ k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __
 // anywhere in the table carries a smaller call number.
 // Replicas spread the atomics of a slot that many blocks feed (one cluster spanning all channels: every block).
 // ---------------------------------------------------------------------------------------------
-typedef unsigned long long u64;
-
-// order-preserving key of a float for an unsigned maximum; NaN maps to the largest key (it wins, like torch.amax)
-__device__ __forceinline__ unsigned max_key(float f) {
-    if (f != f) return 0xFFFFFFFFu;
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float max_key_value(unsigned k) {
-    if (k == 0xFFFFFFFFu) return __builtin_nanf("");
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
-// the same for a minimum: the complemented key, NaN again the largest
-__device__ __forceinline__ unsigned min_key(float f) { return (f != f) ? 0xFFFFFFFFu : ~max_key(f); }
-__device__ __forceinline__ float min_key_value(unsigned k) {
-    if (k == 0xFFFFFFFFu) return __builtin_nanf("");
-    return max_key_value(~k);
-}
-
-// slot of channel c: by arithmetic for equal-sized clusters (csize > 0), through the map otherwise
-struct SlotMap {
-    const int* slot_of;  // [C] or nullptr when csize > 0
-    int csize;           // size of every cluster, or 0
-    int covered;         // channels that belong to a cluster
-    int ncl;
-    __device__ __forceinline__ int operator()(long long c) const {
-        if (csize > 0) return c < covered ? (int)(c / csize) : ncl + (int)(c - covered);
-        return slot_of[c];
-    }
-};
-constexpr int kSlotStride = 16;  // 64-bit words per slot replica: one 128-byte line each, so that the atomics of
-                                 // different slots (and replicas) are served by different cache lines
-constexpr int kMaxSlabs = 8;     // slabs of one shape per launch (grid.z)
-struct SlabPtrs { const void* p[kMaxSlabs]; };
-struct SlabOuts { void* p[kMaxSlabs]; };
-
 // Statistics pass.  Block = 4 waves; lane l owns one 16-byte pack of channels, wave w the rows r0 + w, r0 + w + 4, ...
 // of the block's row chunk with DEPTH rows in flight (every wave-load is one contiguous 1 KiB segment; rows past the
 // chunk's end are replaced by its last row, which changes no minimum or maximum).  blockIdx.z selects the slab; slab i
@@ -753,10 +718,6 @@ extern "C" int miq_act_calib_quant_fwd(const void* x, const void* cached_min, co
 // ---------------------------------------------------------------------------------------------
 // fresh statistics: statistics kernel + quantize kernel over up to kMaxSlabs slabs of one shape
 // ---------------------------------------------------------------------------------------------
-constexpr int kSlotReplicas = 8;  // replicas the workspace is sized for
-
-static inline int64_t fresh_slots(int64_t C, int n_clusters, int64_t covered) { return (int64_t)n_clusters + (C - covered); }
-static inline int64_t fresh_table_words(int64_t nslot) { return (int64_t)kSlotStride * nslot * kSlotReplicas; }
 
 extern "C" int64_t miq_act_fresh_workspace(int n, int64_t C, int n_clusters, int64_t covered) {
     if (n <= 0 || C <= 0 || n_clusters < 0 || covered < 0 || covered > C) return 0;
@@ -819,6 +780,53 @@ static int act_fresh_t(int n, const void* const* x, int64_t cluster_size, const 
     }
     MIQ_CHECK_LAUNCH("miq_act_fresh_quant_fwd");
     return 0;
+}
+
+// The quantize half alone, for one slab whose statistics a producer other than k_colstat_slots has published in slab 0
+// of `workspace` with kSlotReplicas replicas (the norm kernels do, for their own output).
+template <typename T>
+static int act_from_table_t(const void* x, int64_t cluster_size, const int* slot_of, int n_clusters, int64_t covered, int n_bits,
+                            void* workspace, void* out, void* codes_out, void* stats_out, long long R, long long C,
+                            hipStream_t stream) {
+    constexpr int N = VecOf<T>::N;
+    MIQ_CHECK_ARG(C % N == 0 && aligned16(x) && aligned16(out) && aligned16(stats_out) &&
+                      (!codes_out || (reinterpret_cast<uintptr_t>(codes_out) % N) == 0),
+                  "miq_act_quant_from_table: C must be a multiple of %d and the pointers 16-byte aligned", N);
+    SlabPtrs xs{};
+    SlabOuts outs{}, codes{}, vecs{};
+    xs.p[0] = x; outs.p[0] = out; codes.p[0] = codes_out; vecs.p[0] = stats_out;
+    const int tiles = (int)((C / N + 63) / 64);
+    const int nchunk = pick_chunks(R, tiles);
+    const int rpc = (int)((R + nchunk - 1) / nchunk);
+    const SlotMap sm{cluster_size > 0 ? nullptr : slot_of, (int)cluster_size, (int)covered, n_clusters};
+    const long long ws_stride = fresh_table_words(fresh_slots(C, n_clusters, covered));
+    const bool uniform = cluster_size > 0 && cluster_size % N == 0 && covered == C;
+    const float qmax = (float)((1 << n_bits) - 1);
+    launch_fresh_quant<T, N, kSlotReplicas>(uniform, dim3(tiles, nchunk, 1), stream, xs, sm, static_cast<u64*>(workspace), ws_stride,
+                                            outs, codes, vecs, R, (int)C, rpc, qmax);
+    MIQ_CHECK_LAUNCH("miq_act_quant_from_table");
+    return 0;
+}
+
+extern "C" int miq_act_quant_from_table(const void* x, int64_t cluster_size, const int* slot_of, int n_clusters, int64_t covered,
+                                        int n_bits, void* workspace, void* out, void* codes_out, void* stats_out, int64_t R,
+                                        int64_t C, int dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(x && out && stats_out && workspace && R > 0 && C > 0 && C < (1ll << 31),
+                  "miq_act_quant_from_table: null pointer or bad shape (R=%lld C=%lld)", (long long)R, (long long)C);
+    MIQ_CHECK_ARG(n_clusters >= 0 && covered >= 0 && covered <= C && (cluster_size > 0 || slot_of || n_clusters == 0),
+                  "miq_act_quant_from_table: unequal clusters need the channel -> slot map");
+    MIQ_CHECK_ARG(cluster_size <= 0 || cluster_size * n_clusters == covered, "miq_act_quant_from_table: cluster_size * n_clusters != covered");
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15 && (!codes_out || n_bits <= 8), "miq_act_quant_from_table: n_bits=%d unsupported", n_bits);
+    MIQ_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 127u) == 0, "miq_act_quant_from_table: workspace must be 128-byte aligned");
+    if (dtype == MIQ_F32)
+        return act_from_table_t<float>(x, cluster_size, slot_of, n_clusters, covered, n_bits, workspace, out, codes_out, stats_out, R, C,
+                                       (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return act_from_table_t<__half>(x, cluster_size, slot_of, n_clusters, covered, n_bits, workspace, out, codes_out, stats_out, R, C,
+                                        (hipStream_t)stream);
+    miq_set_error("miq_act_quant_from_table: unsupported dtype %d", dtype);
+    return -22;
 }
 
 extern "C" int miq_act_fresh_quant_fwd(int n, const void* const* x, int64_t cluster_size, const int* slot_of, int n_clusters,

@@ -9,6 +9,7 @@
 //             d_weight[c] = sum_r gy*u and d_bias[c] = sum_r gy, then a deterministic fold of the chunks.
 // All arithmetic in fp32 like the reference (every intermediate there is an fp32 tensor); the output is rounded once.
 #include "miq_common.h"
+#include "slot_table.h"
 
 namespace miq {
 
@@ -21,47 +22,78 @@ struct RmsArgs {
     int C;
 };
 
-template <typename TX, int VEC, int TEAM, int NV>
+// STATS: the kernel also folds the minima / maxima of the values it stores (after rounding to TX) into the slot table
+// of `sink`, which is what the statistics pass of the activation quantizer would compute from `out`.  A team then walks
+// kStatRows consecutive rows, keeps the running extremes of its channels in registers and publishes once (a quarter of
+// the exchanges and atomics of one row per team); a team past the last row repeats the last row (same stores, same
+// statistics) so that every lane takes part in the exchange.
+template <typename TX, int VEC, int TEAM, int NV, bool STATS>
 __global__ void __launch_bounds__(block_of<TEAM>())
-k_rmsnorm_fwd(RmsArgs a, TX* __restrict__ out, float* __restrict__ rstd_out) {
+k_rmsnorm_fwd(RmsArgs a, TX* __restrict__ out, float* __restrict__ rstd_out, RowStatSink sink) {
     static_assert(VEC == 4, "the weight / bias vectors are read as float4");
     __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
+    constexpr int ROWS = STATS ? kStatRows : 1;
     const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= a.R) return;  // TEAM > 64 implies one row per block: block-uniform where barriers follow
-    RowTile<TX, VEC, TEAM, NV> x;
-    x.load(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
-    float ss[1] = {0.f};
+    const long long row0 = ((long long)blockIdx.x * RPB + threadIdx.x / TEAM) * ROWS;
+    unsigned tag = 0;
+    if (STATS) {
+        tag = (unsigned)sink.ws[0] + 1u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sink.ws[1] = tag;
+    } else if (row0 >= a.R) {
+        return;  // TEAM > 64 implies one row per block: block-uniform where barriers follow
+    }
+    float lo[STATS ? NV : 1][VEC], hi[STATS ? NV : 1][VEC];
+    if constexpr (STATS) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
+        for (int k = 0; k < NV; ++k)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float v = to_f<TX>(x.v[k].e[e]);
-            ss[0] += v * v;
+            for (int e = 0; e < VEC; ++e) { lo[k][e] = __builtin_inff(); hi[k][e] = -__builtin_inff(); }
+    }
+#pragma unroll 1
+    for (int it = 0; it < ROWS; ++it) {
+        long long row = row0 + it;
+        if (row >= a.R) row = a.R - 1;  // STATS only
+        RowTile<TX, VEC, TEAM, NV> x;
+        x.load(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
+        float ss[1] = {0.f};
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float v = to_f<TX>(x.v[k].e[e]);
+                ss[0] += v * v;
+            }
+        }
+        team_sum<TEAM, 1>(ss, lds);
+        const float rstd = 1.0f / sqrtf(ss[0] / (float)a.C + a.eps);
+        if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            const long long c0 = x.offset(k);
+            // VEC == 4: one 16-byte load per vector and pack (the entry point checks the alignment)
+            const float4 w4 = *reinterpret_cast<const float4*>(a.weight + c0);
+            const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+            Pack<TX, VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float y = wv[e] * (to_f<TX>(x.v[k].e[e]) * rstd);
+                if (a.bias) y += bv[e];
+                o.e[e] = from_f<TX>(y);
+                if constexpr (STATS) {
+                    const float stored = to_f<TX>(o.e[e]);
+                    lo[k][e] = nmin(lo[k][e], stored);
+                    hi[k][e] = nmax(hi[k][e], stored);
+                }
+            }
+            st_pack<TX, VEC>(out + row * a.C + c0, o);
         }
     }
-    team_sum<TEAM, 1>(ss, lds);
-    const float rstd = 1.0f / sqrtf(ss[0] / (float)a.C + a.eps);
-    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
-        const long long c0 = x.offset(k);
-        // VEC == 4: one 16-byte load per vector and pack (the entry point checks the alignment)
-        const float4 w4 = *reinterpret_cast<const float4*>(a.weight + c0);
-        const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        Pack<TX, VEC> o;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float y = wv[e] * (to_f<TX>(x.v[k].e[e]) * rstd);
-            if (a.bias) y += bv[e];
-            o.e[e] = from_f<TX>(y);
-        }
-        st_pack<TX, VEC>(out + row * a.C + c0, o);
-    }
+    if constexpr (STATS)
+        publish_minmax<TEAM, NV, VEC>(sink, lo, hi, lane, a.C / VEC, (int)((row0 / ROWS) % kSlotReplicas), tag, lds);
 }
 
 template <typename TX, int VEC, int TEAM, int NV>
@@ -176,14 +208,16 @@ static inline int rms_chunks(long long R, long long C) {
 }
 
 template <typename TX>
-static void rms_fwd_launch(const RmsArgs& a, void* out, float* rstd, hipStream_t stream) {
+static void rms_fwd_launch(const RmsArgs& a, void* out, float* rstd, const RowStatSink& sink, hipStream_t stream) {
     constexpr int VEC = 4;  // 16-byte fp32 / 8-byte fp16 accesses, one tiling for both
     const int npack = a.C / VEC;
-#define L(TEAM, NV)                                                                                          \
-    {                                                                                                        \
-        constexpr int RPB = block_of<TEAM>() / TEAM;                                                         \
-        hipLaunchKernelGGL((k_rmsnorm_fwd<TX, VEC, TEAM, NV>), dim3((unsigned)((a.R + RPB - 1) / RPB)),      \
-                           dim3(block_of<TEAM>()), 0, stream, a, (TX*)out, rstd);                            \
+#define L(TEAM, NV)                                                                                                  \
+    {                                                                                                                \
+        constexpr int RPB = block_of<TEAM>() / TEAM;                                                                 \
+        const long long per = (long long)RPB * (sink.ws ? kStatRows : 1); /* rows per block */                       \
+        const dim3 grid((unsigned)((a.R + per - 1) / per)), block(block_of<TEAM>());                                 \
+        if (sink.ws) hipLaunchKernelGGL((k_rmsnorm_fwd<TX, VEC, TEAM, NV, true>), grid, block, 0, stream, a, (TX*)out, rstd, sink); \
+        else hipLaunchKernelGGL((k_rmsnorm_fwd<TX, VEC, TEAM, NV, false>), grid, block, 0, stream, a, (TX*)out, rstd, sink);        \
     }
     MIQ_ROW_DISPATCH(npack, L);
 #undef L
@@ -225,20 +259,49 @@ extern "C" int64_t miq_rmsnorm_workspace(int64_t R, int64_t C) {
     return 2ll * rms_chunks(R, C) * C;
 }
 
+static int rmsnorm_fwd_checked(const char* who, const void* x, const float* weight, const float* bias, void* out, float* rstd_out,
+                               int64_t R, int64_t C, float eps, int dtype, const RowStatSink& sink, void* stream) {
+    MIQ_CHECK_ARG(x && weight && out && R > 0 && C > 0 && C < (1ll << 31), "%s: null pointer or bad shape", who);
+    MIQ_CHECK_ARG(C % 4 == 0 && C / 4 <= kRowMaxPacks, "%s: C=%lld must be a multiple of 4 and at most %d", who, (long long)C,
+                  4 * kRowMaxPacks);
+    MIQ_CHECK_ARG(dtype == MIQ_F32 || dtype == MIQ_F16, "%s: unsupported dtype %d", who, dtype);
+    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(out) && is_aligned16(weight) && is_aligned16(bias),
+                  "%s: x / out / weight / bias must be 16-byte aligned", who);
+    RmsArgs a{x, weight, bias, eps, R, (int)C};
+    if (dtype == MIQ_F32) rms_fwd_launch<float>(a, out, rstd_out, sink, (hipStream_t)stream);
+    else rms_fwd_launch<__half>(a, out, rstd_out, sink, (hipStream_t)stream);
+    MIQ_CHECK_LAUNCH(who);
+    return 0;
+}
+
 extern "C" int miq_rmsnorm_fwd(const void* x, const float* weight, const float* bias, void* out, float* rstd_out, int64_t R,
                                int64_t C, float eps, int dtype, void* stream) {
     if (R == 0 || C == 0) return 0;
-    MIQ_CHECK_ARG(x && weight && out && R > 0 && C > 0 && C < (1ll << 31), "miq_rmsnorm_fwd: null pointer or bad shape");
-    MIQ_CHECK_ARG(C % 4 == 0 && C / 4 <= kRowMaxPacks, "miq_rmsnorm_fwd: C=%lld must be a multiple of 4 and at most %d", (long long)C,
-                  4 * kRowMaxPacks);
-    MIQ_CHECK_ARG(dtype == MIQ_F32 || dtype == MIQ_F16, "miq_rmsnorm_fwd: unsupported dtype %d", dtype);
-    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(out) && is_aligned16(weight) && is_aligned16(bias),
-                  "miq_rmsnorm_fwd: x / out / weight / bias must be 16-byte aligned");
-    RmsArgs a{x, weight, bias, eps, R, (int)C};
-    if (dtype == MIQ_F32) rms_fwd_launch<float>(a, out, rstd_out, (hipStream_t)stream);
-    else rms_fwd_launch<__half>(a, out, rstd_out, (hipStream_t)stream);
-    MIQ_CHECK_LAUNCH("miq_rmsnorm_fwd");
+    return rmsnorm_fwd_checked("miq_rmsnorm_fwd", x, weight, bias, out, rstd_out, R, C, eps, dtype, RowStatSink{nullptr, 0, nullptr}, stream);
+}
+
+// the statistics sink of the *_fwd_stats entry points, checked: equal clusters (multiples of the 4-channel pack) that
+// cover every channel go by arithmetic, everything else through the channel -> slot map
+int miq_row_stat_sink(const char* who, int64_t cluster_size, const int* slot_of, int n_clusters, int64_t covered, int64_t C,
+                      void* stat_workspace, RowStatSink* sink) {
+    MIQ_CHECK_ARG(stat_workspace && (reinterpret_cast<uintptr_t>(stat_workspace) & 127u) == 0,
+                  "%s: the statistics workspace must be 128-byte aligned", who);
+    MIQ_CHECK_ARG(n_clusters >= 0 && covered >= 0 && covered <= C && (cluster_size <= 0 || cluster_size * n_clusters == covered),
+                  "%s: bad cluster layout", who);
+    const bool by_arithmetic = cluster_size > 0 && cluster_size % 4 == 0 && covered == C;
+    MIQ_CHECK_ARG(by_arithmetic || slot_of, "%s: this cluster layout needs the channel -> slot map", who);
+    *sink = RowStatSink{static_cast<u64*>(stat_workspace), by_arithmetic ? (int)(cluster_size / 4) : 0, by_arithmetic ? nullptr : slot_of};
     return 0;
+}
+
+extern "C" int miq_rmsnorm_fwd_stats(const void* x, const float* weight, const float* bias, void* out, float* rstd_out, int64_t R,
+                                     int64_t C, float eps, int dtype, int64_t cluster_size, const int* slot_of, int n_clusters,
+                                     int64_t covered, void* stat_workspace, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    RowStatSink sink{};
+    if (const int rc = miq_row_stat_sink("miq_rmsnorm_fwd_stats", cluster_size, slot_of, n_clusters, covered, C, stat_workspace, &sink))
+        return rc;
+    return rmsnorm_fwd_checked("miq_rmsnorm_fwd_stats", x, weight, bias, out, rstd_out, R, C, eps, dtype, sink, stream);
 }
 
 extern "C" int miq_rmsnorm_bwd(const void* grad_out, const void* x, const float* weight, const float* rstd, void* dx,

@@ -41,6 +41,7 @@ def lib() -> ctypes.CDLL:
         _lib.miq_act_fresh_bwd_workspace.restype = ctypes.c_int64
         _lib.miq_let_workspace.restype = ctypes.c_int64
         _lib.miq_rmsnorm_workspace.restype = ctypes.c_int64
+        _lib.miq_gather_layernorm_bwd_workspace.restype = ctypes.c_int64
         _lib.miq_col_sum_workspace.restype = ctypes.c_int64
         _lib.miq_mse_workspace.restype = ctypes.c_int64
     return _lib

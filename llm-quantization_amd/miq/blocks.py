@@ -21,7 +21,7 @@ from .int_linear import QuantLinear
 from .int_matmul import QuantMatMul
 from .let import LetPlan, LinearStep, NormStep, truncate_number
 from .omni_norm import OmniLayerNorm, OmniLlamaRMSNorm
-from .quantizer import batched_static_quant, shared_static_quant
+from .quantizer import batched_static_quant, norm_shared_quant, shared_static_quant
 
 TRUNCATE_THRESHOLD = 1e-2  # truncate_number's default where the decoder layers call it (models/transformation.py:18)
 
@@ -261,12 +261,22 @@ class _BlockBase(nn.Module):
 SHARE_ACT_QUANT = True  # module-wide switch (A/B timing): one activation-quantizer evaluation for layers reading one tensor
 
 
-def _linears_on_one_input(linears, x):
-    """[lin(x) for lin in linears] with the input quantized once when the layers' activation quantizers cannot differ."""
+def _linears_on_one_input(linears, x, pre_norm=None):
+    """[lin(x) for lin in linears] (x = pre_norm(x) first when a norm is given) with the input quantized once when the
+    layers' activation quantizers cannot differ, and the quantizer's statistics gathered by the norm kernel when it
+    calibrates on fresh statistics."""
     if SHARE_ACT_QUANT and all(m.use_act_quant and not m.disable_input_quant for m in linears):
-        xq = shared_static_quant([m.act_quantizer for m in linears], x)
+        qs = [m.act_quantizer for m in linears]
+        if pre_norm is not None:
+            xq = norm_shared_quant(pre_norm, qs, x)
+            if xq is not None:
+                return [m(xq, input_quantized=True) for m in linears]
+            x, pre_norm = pre_norm(x), None
+        xq = shared_static_quant(qs, x)
         if xq is not None:
             return [m(xq, input_quantized=True) for m in linears]
+    if pre_norm is not None:
+        x = pre_norm(x)
     return [m(x) for m in linears]
 
 
@@ -301,9 +311,9 @@ class _OPTAttention(nn.Module):
     def _heads(self, t, bsz):
         return t.view(bsz, -1, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
 
-    def forward(self, hidden_states, attention_mask=None):
+    def forward(self, hidden_states, attention_mask=None, pre_norm=None):
         bsz, tgt_len, _ = hidden_states.size()
-        q, k, v = _linears_on_one_input([self.q_proj, self.k_proj, self.v_proj], hidden_states)
+        q, k, v = _linears_on_one_input([self.q_proj, self.k_proj, self.v_proj], hidden_states, pre_norm)
         q, k, v = _quant_operands([(self.qkt_matmul, 1), (self.qkt_matmul, 2), (self.pv_matmul, 2)], [q * self.scaling, k, v])
         k, v = self._heads(k, bsz), self._heads(v, bsz)
         shape = (bsz * self.num_heads, -1, self.head_dim)
@@ -369,14 +379,13 @@ class QuantOPTBlock(_BlockBase):
 
     def forward(self, hidden_states, attention_mask=None, **_kw):
         residual = hidden_states
-        h = self.self_attn_layer_norm(hidden_states)
-        h = self.self_attn(h, attention_mask=attention_mask)
+        h = self.self_attn(hidden_states, attention_mask=attention_mask, pre_norm=self.self_attn_layer_norm)
         h = residual + h
         shape = h.shape
         h = h.reshape(-1, h.size(-1))
         residual = h
-        h = self.final_layer_norm(h)
-        h = self.fc2(TF.relu(self.fc1(h)))
+        (h,) = _linears_on_one_input([self.fc1], h, self.final_layer_norm)
+        h = self.fc2(TF.relu(h))
         return ((residual + h).view(shape),)
 
     def let_plan(self) -> LetPlan:
@@ -461,9 +470,9 @@ class _LlamaAttention(nn.Module):
         self.pv_matmul = QuantMatMul(args.p_quant_params, args.v_quant_params, matmul_func=torch.matmul)
         self.fused_softmax = True
 
-    def forward(self, hidden_states, attention_mask=None, position_ids=None):
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, pre_norm=None):
         bsz, q_len, _ = hidden_states.size()
-        q, k, v = _linears_on_one_input([self.q_proj, self.k_proj, self.v_proj], hidden_states)
+        q, k, v = _linears_on_one_input([self.q_proj, self.k_proj, self.v_proj], hidden_states, pre_norm)
         q = q.view(bsz, q_len, self.num_heads, self.head_dim).transpose(1, 2)
         k = k.view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
         v = v.view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
@@ -502,8 +511,8 @@ class _LlamaMLP(nn.Module):
         self.down_proj = QuantLinear(down, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("down", []), **kw)
         self.up_proj = QuantLinear(up, args.weight_quant_params, args.act_quant_params, weight_nbits=nb.get("up", []), **kw)
 
-    def forward(self, x):
-        gate, up = _linears_on_one_input([self.gate_proj, self.up_proj], x)
+    def forward(self, x, pre_norm=None):
+        gate, up = _linears_on_one_input([self.gate_proj, self.up_proj], x, pre_norm)
         return self.down_proj(TF.silu(gate) * up)
 
 
@@ -535,11 +544,10 @@ class QuantLlamaBlock(_BlockBase):
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, **_kw):
         residual = hidden_states
-        h = self.input_layernorm(hidden_states)
-        h = self.self_attn(h, attention_mask=attention_mask, position_ids=position_ids)
+        h = self.self_attn(hidden_states, attention_mask=attention_mask, position_ids=position_ids, pre_norm=self.input_layernorm)
         h = residual + h
         residual = h
-        h = self.mlp(self.post_attention_layernorm(h))
+        h = self.mlp(h, pre_norm=self.post_attention_layernorm)
         return (residual + h,)
 
     def let_plan(self) -> LetPlan:

@@ -226,8 +226,10 @@ class ClusterLayout:
 
     @property
     def slot_of(self):
-        if self.cluster_size:
-            return None
+        """The channel -> slot map of layouts whose slots are not found by arithmetic (None for equal clusters)."""
+        return None if self.cluster_size else self.slot_map()
+
+    def slot_map(self):
         if self._slot_of is None:
             slot = []
             for k, n in enumerate(self._counts):
@@ -495,10 +497,44 @@ def gather_layernorm_fwd(x, idx_i32, weight, bias, eps: float, out_dtype=None):
     return out, mean, rstd
 
 
+def gather_layernorm_bwd(gy, x, idx_i32, weight, mean, rstd, need_dx=True, need_dw=False, need_db=False):
+    """(dx | None, d_weight | None, d_bias | None) of layer_norm(index_select(x, -1, idx), weight, bias) from the saved
+    row statistics (miq_gather_layernorm_bwd); d_weight / d_bias are fp32 [C]."""
+    gy = gy.contiguous()
+    dev = L.check_gpu(gy, x, idx_i32, weight, mean, rstd)
+    C = x.shape[-1]
+    R = x.numel() // C
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty(C, dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.empty(C, dtype=torch.float32, device=dev) if need_db else None
+    ws = None
+    if need_dw or need_db:
+        ws = torch.empty(int(L.lib().miq_gather_layernorm_bwd_workspace(L.i64(R), L.i64(C))), dtype=torch.float32, device=dev)
+    w_code = L._DT[weight.dtype] if weight is not None else L.F32
+    with L.on_device(dev):
+        L.call("miq_gather_layernorm_bwd", L.ptr(gy), L.ptr(x), L.ptr(idx_i32), L.ptr(weight), L.ptr(mean), L.ptr(rstd), L.ptr(dx),
+               L.ptr(dw), L.ptr(db), L.ptr(ws), L.i64(R), L.i64(C), L.i32(L.dtype_code(x)), L.i32(w_code), L.i32(L.dtype_code(gy)),
+               L.stream_of(x))
+    return dx, dw, db
+
+
+def _ln_backward(ctx_needs, gy, x, idx, w, b, mean, rstd):
+    """Shared backward of the gather + LayerNorm functions: gradients for (x, weight, bias)."""
+    need_w = w is not None and ctx_needs[1]
+    need_b = b is not None and ctx_needs[2]
+    if gy.dtype not in (torch.float16, torch.float32):
+        gy = gy.float()
+    dx, dw, db = gather_layernorm_bwd(gy, x, idx, w, mean, rstd, ctx_needs[0], need_w, need_b)
+    if dw is not None:
+        dw = dw.to(w.dtype)
+    if db is not None:
+        db = db.to(b.dtype)
+    return dx, dw, db
+
+
 class GatherLayerNorm(torch.autograd.Function):
-    """layer_norm(index_select(x, -1, idx), weight, bias): fused forward kernel; the backward recomputes the
-    gathered row with the gather kernel, uses ATen's LayerNorm backward on the saved mean / rstd and routes
-    dx back through the inverse permutation."""
+    """layer_norm(index_select(x, -1, idx), weight, bias): one kernel forward; backward one row kernel (the scatter
+    through the index happens in LDS) plus the column sums of d_weight / d_bias when they are needed."""
 
     @staticmethod
     def forward(ctx, x, idx_i32, inv_i32, weight, bias, eps, out_dtype):
@@ -506,27 +542,15 @@ class GatherLayerNorm(torch.autograd.Function):
         w = None if weight is None else weight.contiguous()
         b = None if bias is None else bias.contiguous()
         y, mean, rstd = gather_layernorm_fwd(x, idx_i32, w, b, eps, out_dtype)
-        ctx.save_for_backward(x, idx_i32, inv_i32, w, b, mean, rstd)
+        ctx.save_for_backward(x, idx_i32, w, b, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, idx, inv, w, b, mean, rstd = ctx.saved_tensors
-        xg = gather_lastdim(x, idx) if idx is not None else x
-        cdt = gy.dtype
-        mask = [ctx.needs_input_grad[0], w is not None and ctx.needs_input_grad[3], b is not None and ctx.needs_input_grad[4]]
-        dxg, dw, db = torch.ops.aten.native_layer_norm_backward(
-            gy.contiguous(), xg.to(cdt), [x.shape[-1]], mean, rstd, None if w is None else w.to(cdt),
-            None if b is None else b.to(cdt), mask)
-        dx = None
-        if mask[0]:
-            dxg = dxg.to(x.dtype)
-            dx = gather_lastdim(dxg.contiguous(), inv) if idx is not None else dxg
-        if dw is not None and w is not None:
-            dw = dw.to(w.dtype)
-        if db is not None and b is not None:
-            db = db.to(b.dtype)
-        return dx, None, None, dw if mask[1] else None, db if mask[2] else None, None, None
+        x, idx, w, b, mean, rstd = ctx.saved_tensors
+        needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+        dx, dw, db = _ln_backward(needs, gy, x, idx, w, b, mean, rstd)
+        return dx, None, None, dw, db, None, None
 
 
 def masked_softmax_supported(scores, mask) -> bool:
@@ -622,6 +646,121 @@ class RMSNorm(torch.autograd.Function):
             L.call("miq_rmsnorm_bwd", L.ptr(gy), L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws),
                    L.i64(R), L.i64(C), L.i32(L.dtype_code(x)), L.stream_of(x))
         return dx, dw, db, None
+
+
+def _quant_from_table(y2, n_bits, layout, ws):
+    R, C = y2.shape
+    q = torch.empty_like(y2)
+    vec = torch.empty((5, C), dtype=y2.dtype, device=y2.device)
+    L.call("miq_act_quant_from_table", L.ptr(y2), L.i64(layout.cluster_size), L.ptr(layout.slot_of), L.i32(layout.n_clusters),
+           L.i64(layout.covered), L.i32(int(n_bits)), L.ptr(ws), L.ptr(q), None, L.ptr(vec), L.i64(R), L.i64(C),
+           L.i32(L.dtype_code(y2)), L.stream_of(y2))
+    return q, vec
+
+
+def _stat_table(dev, C, layout):
+    nbytes = int(L.lib().miq_act_fresh_workspace(L.i32(1), L.i64(C), L.i32(layout.n_clusters), L.i64(layout.covered)))
+    return _fresh_workspace(dev, nbytes)
+
+
+def _layout_args(layout):
+    """Layout arguments of the norm kernels that publish statistics: their packs are 4 channels wide, so equal clusters of
+    another granularity (or with channels left over) go through the map like unequal ones."""
+    by_arithmetic = layout.cluster_size > 0 and layout.cluster_size % 4 == 0 and layout.covered == layout.C
+    return (L.i64(layout.cluster_size), L.ptr(None if by_arithmetic else layout.slot_map()), L.i32(layout.n_clusters),
+            L.i64(layout.covered))
+
+
+class RMSNormActQuant(torch.autograd.Function):
+    """act_quant(rmsnorm(x)) for a static quantizer calibrating on fresh statistics, in two launches: the norm kernel
+    publishes the minima / maxima of its own output (miq_rmsnorm_fwd_stats), the quantize kernel follows
+    (miq_act_quant_from_table).  Same values as RMSNorm.apply followed by ActCalibFQ.apply.  holder receives the
+    statistics dictionary; returns the quantized tensor."""
+
+    _calls = 0  # forward evaluations so far (tests use it to see that a block took this path)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, n_bits, layout, holder):
+        RMSNormActQuant._calls += 1
+        x = x.contiguous()
+        w = weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        dev = L.check_gpu(x, w, b)
+        C = x.shape[-1]
+        R = x.numel() // C
+        y = torch.empty_like(x)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        with L.on_device(dev):
+            ws = _stat_table(dev, C, layout)
+            L.call("miq_rmsnorm_fwd_stats", L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(rstd), L.i64(R), L.i64(C),
+                   L.f32(float(eps)), L.i32(L.dtype_code(x)), *_layout_args(layout), L.ptr(ws), L.stream_of(x))
+            q, vec = _quant_from_table(y.reshape(R, C), n_bits, layout, ws)
+        holder.update(stats_of(vec))
+        ctx.save_for_backward(x, w, rstd, y, vec)
+        ctx.has_bias, ctx.n_bits, ctx.layout = b is not None, n_bits, layout
+        return q.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, gq):
+        x, w, rstd, y, vec = ctx.saved_tensors
+        C = x.shape[-1]
+        y2 = y.reshape(-1, C)
+        gy = act_fresh_quant_bwd([gq.contiguous().reshape(y2.shape)], [y2], [vec], ctx.n_bits, ctx.layout)[0]
+        R = y2.shape[0]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty(C, dtype=torch.float32, device=x.device) if need_w else None
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if need_b else None
+        ws = None
+        if need_w or need_b:
+            ws = torch.empty(int(L.lib().miq_rmsnorm_workspace(L.i64(R), L.i64(C))), dtype=torch.float32, device=x.device)
+        with L.on_device(x.device):
+            L.call("miq_rmsnorm_bwd", L.ptr(gy), L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws),
+                   L.i64(R), L.i64(C), L.i32(L.dtype_code(x)), L.stream_of(x))
+        return dx, dw, db, None, None, None, None
+
+
+class GatherLayerNormActQuant(torch.autograd.Function):
+    """act_quant(layer_norm(index_select(x, -1, idx))) for a static quantizer calibrating on fresh statistics, in two
+    launches (miq_gather_layernorm_fwd_stats, miq_act_quant_from_table).  Same values as GatherLayerNorm.apply followed by
+    ActCalibFQ.apply."""
+
+    _calls = 0
+
+    @staticmethod
+    def forward(ctx, x, idx_i32, weight, bias, eps, out_dtype, n_bits, layout, holder):
+        GatherLayerNormActQuant._calls += 1
+        x = x.contiguous()
+        w = None if weight is None else weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        dev = L.check_gpu(x, idx_i32, w, b)
+        C = x.shape[-1]
+        R = x.numel() // C
+        y = torch.empty_like(x, dtype=out_dtype or x.dtype)
+        mean = torch.empty(R, dtype=torch.float32, device=dev)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        wb = w if w is not None else b
+        w_code = L._DT[wb.dtype] if wb is not None else L.F32
+        with L.on_device(dev):
+            ws = _stat_table(dev, C, layout)
+            L.call("miq_gather_layernorm_fwd_stats", L.ptr(x), L.ptr(idx_i32), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                   L.i64(R), L.i64(C), L.f32(float(eps)), L.i32(L.dtype_code(x)), L.i32(w_code), L.i32(L.dtype_code(y)),
+                   *_layout_args(layout), L.ptr(ws), L.stream_of(x))
+            q, vec = _quant_from_table(y.reshape(R, C), n_bits, layout, ws)
+        holder.update(stats_of(vec))
+        ctx.save_for_backward(x, idx_i32, w, b, mean, rstd, y, vec)
+        ctx.n_bits, ctx.layout = n_bits, layout
+        return q.reshape(y.shape)
+
+    @staticmethod
+    def backward(ctx, gq):
+        x, idx, w, b, mean, rstd, y, vec = ctx.saved_tensors
+        y2 = y.reshape(-1, y.shape[-1])
+        gy = act_fresh_quant_bwd([gq.contiguous().reshape(y2.shape)], [y2], [vec], ctx.n_bits, ctx.layout)[0]
+        needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        dx, dw, db = _ln_backward(needs, gy, x, idx, w, b, mean, rstd)
+        return dx, None, dw, db, None, None, None, None, None
 
 
 FUSED_MSE = True  # module-wide switch of mse_loss's kernel path (A/B timing)

@@ -361,3 +361,78 @@ def test_half_weight_path_under_autocast_equals_quantize_then_cast(let):
     assert torch.equal(o1, o0)
     for n in g0:
         assert rel_err(g1[n].cpu(), g0[n].cpu()) <= 2e-3, (n, rel_err(g1[n].cpu(), g0[n].cpu()))
+
+
+@pytest.mark.parametrize("kind", ["llama", "opt_reordered"])
+def test_norm_kernels_that_gather_statistics_equal_the_separate_kernels(kind):
+    """Layer norm -> shared activation quantizer with the quantizer's statistics folded into the norm kernel (RMSNorm for
+    the Llama block with per-tensor statistics; gather + LayerNorm for the reordered OPT block with k-means clusters of
+    unequal sizes) against the norm followed by the statistics kernel: same loss to the last bit, same activation
+    scales, parameter gradients up to summation order."""
+    import miq.quantizer as Q
+    from miq import functional as F
+    from miq import reorder_utils as R
+    if kind == "llama":
+        d = golden("block_llama")["llama_tiny_w4a4_pertensor"]
+        builder, prefix, sites, is_llama, shifts = build, PREFIX, LET_SITES, True, {}
+    else:
+        import test_gpu_block_calibration as opt
+        from miq.calibrate import reorder_block
+        d = golden("block")["opt_tiny_w4a4_reorder"]
+        prefix, is_llama = "model.decoder.layers.0", False
+        sites = ("self_attn.q_proj", "self_attn.out_proj", "fc1")
+        shifts = {f"{prefix}.{n}": d[f"act_shift_{n}"] for n in sites}
+
+        def builder(dd):
+            q = opt.build(dd)
+            mm = dd["meta"]
+            R.oc_maxmin_dict.clear()
+            R.ic_maxmin_dict.clear()
+            for name in ("self_attn_layer_norm", "self_attn.q_proj", "self_attn.k_proj", "final_layer_norm"):
+                R.oc_maxmin_dict[name] = (dd[f"stat_oc_{name}_max"].to(DEV), dd[f"stat_oc_{name}_min"].to(DEV))
+            for name in ("self_attn.out_proj", "fc2"):
+                R.ic_maxmin_dict[name] = (dd[f"stat_ic_{name}_max"].to(DEV), dd[f"stat_ic_{name}_min"].to(DEV))
+            reorder_block(q, mm["H"], mm["F"], mm["heads"], {f"R{k}": True for k in range(1, 6)}, mm["clusters"], DEV)
+            R.oc_maxmin_dict.clear()
+            R.ic_maxmin_dict.clear()
+            return q
+    m = d["meta"]
+    cfg = config(m)
+    act_scales = {f"{prefix}.{n}": d[f"act_scale_{n}"] for n in sites}
+    x, y = d["inps"][:2].to(DEV), d["fp_out"][:2].to(DEV)
+    mask = d["mask"].to(DEV).repeat(2, 1, 1, 1)
+    res, calls = {}, {}
+    keep = (Q.FUSE_NORM_QUANT, Q.FUSE_NORM_QUANT_CLUSTERS, F.TENSOR_FOLD)
+    counted = [F.RMSNormActQuant, F.GatherLayerNormActQuant]
+    try:
+        F.TENSOR_FOLD = False  # (narrow per-tensor slabs are otherwise reshaped by the separate path: other summation order)
+        for fuse in (True, False):
+            Q.FUSE_NORM_QUANT, Q.FUSE_NORM_QUANT_CLUSTERS = fuse, fuse
+            n0 = sum(getattr(c, "_calls", 0) for c in counted)
+            q = builder(d)
+            q.set_quant_state(weight_quant=False, act_quant=True)
+            q.let = True
+            init_let(q, act_scales, shifts, prefix, cfg, None, torch.float32, torch.device(DEV), is_llama=is_llama)
+            with torch.no_grad():
+                q.float()
+            losses = []
+            for _step in range(2):
+                q.zero_grad()
+                q.smooth_and_quant_temporary()
+                loss = torch.nn.functional.mse_loss(q(x, attention_mask=mask)[0], y)
+                loss.backward()
+                losses.append(loss.item())
+                for aq in q.act_quantizers():
+                    aq.free()
+            res[fuse] = (losses, {n: p.grad.clone() for n, p in q.named_parameters() if p.grad is not None},
+                         [aq.scale.clone() for aq in q.act_quantizers() if aq.scale is not None])
+            calls[fuse] = sum(getattr(c, "_calls", 0) for c in counted) - n0
+    finally:
+        Q.FUSE_NORM_QUANT, Q.FUSE_NORM_QUANT_CLUSTERS, F.TENSOR_FOLD = keep
+    assert res[True][0] == res[False][0]
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    assert res[True][1].keys() == res[False][1].keys()
+    for n, g in res[True][1].items():
+        assert rel_err(g, res[False][1][n]) <= 2e-5, n
+    assert calls[True] == 4 and calls[False] == 0  # two norms x two steps went through the fused pair
