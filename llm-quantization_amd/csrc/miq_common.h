@@ -142,6 +142,25 @@ struct UncheckedDivisor {
         return __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
     }
 };
+// x / s for consumers that only round the quotient to an integer level and clamp the level (the uniform grids), given
+// rs = RN(1 / s) and 2^-40 <= |s| <= 2^40 (or a NaN s): the corrected product above wherever it equals the IEEE quotient
+// (2^-80 <= |x * rs| <= 2^100); for smaller products both are far below 0.5 in magnitude and round to the same level;
+// for larger ones, infinite and NaN x the plain product is returned (beyond every level, infinite or NaN like the
+// quotient).  5 VALU operations, no branch, no reciprocal per element.
+__device__ __forceinline__ float level_div(float x, float s, float rs) {
+    const float q0 = x * rs;
+    const float q = __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
+    return fabsf(q0) <= 0x1p100f ? q : q0;
+}
+__device__ __forceinline__ bool level_div_ok(float s) {
+    const float a = fabsf(s);
+    return a >= 0x1p-40f && a <= 0x1p40f;
+}
+struct LevelDivisor {
+    float s, rs;
+    __device__ __forceinline__ explicit LevelDivisor(float s_) : s(s_), rs(1.0f / s_) {}
+    __device__ __forceinline__ float div(float x) const { return level_div(x, s, rs); }
+};
 // divisor types of the arithmetic-bound row kernels
 template <typename T> struct BwdDivisorOf { using type = Divisor<T>; };
 template <> struct BwdDivisorOf<float> { using type = UncheckedDivisor; };
@@ -176,8 +195,8 @@ __device__ __forceinline__ float rint_ste(float q) {
 // The affine quantization level of one element: clamp(round(x/s) + zp, 0, qmax) and the dequantized
 // value (level - zp) * s, with the per-op rounding of T.  `exact_int` tells that |zp| + qmax <= 2048 and
 // qmax < 2048, i.e. every integer intermediate is exactly representable in fp16 (always true for fp32).
-template <typename T>
-__device__ __forceinline__ float affine_level(float x, const Divisor<T>& dv, float zp, bool exact_int) {
+template <typename T, class D>
+__device__ __forceinline__ float affine_level(float x, const D& dv, float zp, bool exact_int) {
     const float xi = rint_ste(dv.div(x)) + zp;
     return exact_int ? xi : rnd<T>(xi);
 }
@@ -196,7 +215,8 @@ template <> __device__ __forceinline__ bool ints_exact<__half>(float zp, float q
 // calibrated scale is clamped to [1e-5, 1e4]; a NaN scale propagates through either path).
 template <typename T>
 __device__ __forceinline__ float col_div(float x, float s, float rs);
-template <> __device__ __forceinline__ float col_div<float>(float x, float s, float) { return x / s; }
+// (the calibrated scale lies in [1e-5, 1e4] or is NaN, and rs is the IEEE 1 / s: level_div applies)
+template <> __device__ __forceinline__ float col_div<float>(float x, float s, float rs) { return level_div(x, s, rs); }
 template <> __device__ __forceinline__ float col_div<__half>(float x, float s, float rs) {
     const float q0 = x * rs;
     const float e = __builtin_fmaf(-q0, s, x);   // exact residual: see Divisor<__half>
@@ -331,9 +351,17 @@ struct RowTile {
 template <typename T, int VEC, int TEAM, int NV>
 __device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, bool padded, float* lds,
                                            float& rmin, float& rmax) {
+    // per element: one minimum, one maximum (the hardware's, which skip NaN; the compiler pairs them into three-operand
+    // forms) and an unordered-compare that remembers a NaN, instead of two compare-and-select chains
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    x.for_each([&](int, int, float a) { mn = nmin(mn, a); mx = nmax(mx, a); });
-    if (padded) { mn = nmin(mn, 0.f); mx = nmax(mx, 0.f); }
+    bool any_nan = false;
+    x.for_each([&](int, int, float a) {
+        mn = __builtin_fminf(mn, a);
+        mx = __builtin_fmaxf(mx, a);
+        any_nan = any_nan || (a != a);
+    });
+    if (padded) { mn = __builtin_fminf(mn, 0.f); mx = __builtin_fmaxf(mx, 0.f); }
+    if (any_nan) mn = mx = __builtin_nanf("");
     float mm[2] = {mn, mx};
     team_reduce<TEAM, 2>(mm, OpMinMax(), lds);
     rmin = mm[0];

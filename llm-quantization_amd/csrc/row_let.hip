@@ -143,18 +143,23 @@ k_let_fwd(LetArgs a, TO* __restrict__ out, float* __restrict__ scale_out, float*
             scale_out[row] = c.s;
             rzp_out[row] = c.rzp;
         }
+        // the level only needs the quotient rounded to an integer: level_div where the scale allows it (nearly always)
+        auto quantize_row = [&](const auto& dv) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (!x.has(k)) continue;
-            Pack<TO, 4> o;
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+                Pack<TO, 4> o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xi = rint_ste(x.v[k].e[e] / c.s) + c.rzp;
-                // TO = __half: the fp32 result rounded once more, i.e. what a cast of the fp32 tensor gives
-                o.e[e] = from_f<TO>((clampf(xi, 0.f, c.qmax) - c.rzp) * c.s);
+                for (int e = 0; e < 4; ++e) {
+                    const float xi = rint_ste(dv.div(x.v[k].e[e])) + c.rzp;
+                    // TO = __half: the fp32 result rounded once more, i.e. what a cast of the fp32 tensor gives
+                    o.e[e] = from_f<TO>((clampf(xi, 0.f, c.qmax) - c.rzp) * c.s);
+                }
+                st_pack<TO, 4>(out + row * a.I + x.offset(k), o);
             }
-            st_pack<TO, 4>(out + row * a.I + x.offset(k), o);
-        }
+        };
+        if (level_div_ok(c.s)) quantize_row(LevelDivisor(c.s));
+        else quantize_row(Divisor<float>(c.s));
     }
 }
 

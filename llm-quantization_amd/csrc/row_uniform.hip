@@ -73,8 +73,8 @@ __device__ __forceinline__ UniCtx uniform_ctx(const UniArgs<T>& a, long long row
 }
 
 // level before clamping: round_ste(x/s) + zp
-template <typename T>
-__device__ __forceinline__ float quant_level(float x, const Divisor<T>& dv, const UniCtx& c, bool exact_int) {
+template <typename T, class D>
+__device__ __forceinline__ float quant_level(float x, const D& dv, const UniCtx& c, bool exact_int) {
     return affine_level<T>(x, dv, c.rzp, exact_int);
 }
 
@@ -99,10 +99,10 @@ __device__ __forceinline__ void uniform_fwd_row(const UniArgs<T>& a, const RowGe
         scale_out[row] = from_f<T>(c.s);
         rzp_out[row] = from_f<T>(c.rzp);
     }
-    const Divisor<T> dv(c.s);
     const bool exact_int = ints_exact<T>(c.rzp, c.qmax);
     // instantiated for both values of exact_int (a per-element test would be a branch around every fp16 re-rounding)
-    auto quantize_row = [&](auto exact_tag) {
+    // and, in fp32, for the two forms of the quotient (a scale outside level_div's range is a row-uniform rarity)
+    auto quantize_row = [&](auto exact_tag, const auto& dv) {
         constexpr bool EX = decltype(exact_tag)::value;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -121,8 +121,14 @@ __device__ __forceinline__ void uniform_fwd_row(const UniArgs<T>& a, const RowGe
             if (codes) st_pack<uint8_t, VEC>(codes + off, cd);
         }
     };
-    if (sizeof(T) == 4 || exact_int) quantize_row(std::true_type{});
-    else quantize_row(std::false_type{});
+    if constexpr (sizeof(T) == 4) {
+        if (level_div_ok(c.s)) quantize_row(std::true_type{}, LevelDivisor(c.s));
+        else quantize_row(std::true_type{}, Divisor<T>(c.s));
+    } else {
+        const Divisor<T> dv(c.s);
+        if (exact_int) quantize_row(std::true_type{}, dv);
+        else quantize_row(std::false_type{}, dv);
+    }
 }
 
 template <typename T, int VEC, int TEAM, int NV>
@@ -202,12 +208,11 @@ __device__ __forceinline__ void uniform_bwd_row(const UniArgs<T>& a, const RowGe
     row_minmax(x, padded, lds, rmin, rmax);
     const UniCtx c = uniform_ctx<T>(a, row, rmin, rmax);
 
-    const Divisor<T> dv(c.s);
     const bool exact_int = ints_exact<T>(c.rzp, c.qmax);
     float acc[3] = {0.f, 0.f, 0.f};  // dS, #elements == rmax, #elements == rmin
     static_assert(NV * VEC <= 64, "mask of un-clamped elements is one 64-bit word");
     unsigned long long inside = 0ull;  // bit k*VEC+e: the level of element (k, e) lies inside the grid
-    auto row_sums = [&](auto exact_tag) {
+    auto row_sums = [&](auto exact_tag, const auto& dv) {
         constexpr bool EX = decltype(exact_tag)::value;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -229,8 +234,16 @@ __device__ __forceinline__ void uniform_bwd_row(const UniArgs<T>& a, const RowGe
             }
         }
     };
-    if (sizeof(T) == 4 || exact_int) row_sums(std::true_type{});
-    else row_sums(std::false_type{});
+    if constexpr (sizeof(T) == 4) {
+        // (the quotient also enters the scale gradient, a tolerance-checked sum: below level_div's exact range it is
+        // ~1e-24 of a level)
+        if (level_div_ok(c.s)) row_sums(std::true_type{}, LevelDivisor(c.s));
+        else row_sums(std::true_type{}, Divisor<T>(c.s));
+    } else {
+        const Divisor<T> dv(c.s);
+        if (exact_int) row_sums(std::true_type{}, dv);
+        else row_sums(std::false_type{}, dv);
+    }
     team_sum<TEAM, 3>(acc, lds);
     if (WANT_DX && padded) {
         const float npad = (float)(geo.g - len);
