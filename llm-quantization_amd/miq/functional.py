@@ -79,18 +79,40 @@ def _ptr_table(tensors):
     return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
 
 
+def _check_batch(xs, ups, lows, gs=None):
+    """The batched row kernels read raw pointer tables: everything they assume about the tensors behind them."""
+    if not xs or len(xs) > 16:
+        raise L.MiqError(f"a batch holds 1..16 matrices, got {len(xs)}")
+    if (ups is None) != (lows is None):
+        raise L.MiqError("LWC factors come in pairs (up and low)")
+    I, dt = xs[0].shape[-1], xs[0].dtype
+    for x in xs:
+        if x.dim() != 2 or x.shape[1] != I or x.dtype != dt or not x.is_contiguous():
+            raise L.MiqError("batched row quantization needs contiguous 2-D matrices of one width and dtype")
+    for name, fs in (("up", ups), ("low", lows)):
+        if fs is None:
+            continue
+        if len(fs) != len(xs):
+            raise L.MiqError(f"{len(fs)} {name} factors for {len(xs)} matrices")
+        for f, x in zip(fs, xs):
+            if f.numel() != x.shape[0] or f.dtype != dt or not f.is_contiguous():
+                raise L.MiqError(f"every {name} factor must be a contiguous tensor of {x.shape[0]} elements of dtype {dt}")
+    if gs is not None:
+        if len(gs) != len(xs):
+            raise L.MiqError(f"{len(gs)} gradients for {len(xs)} matrices")
+        for g, x in zip(gs, xs):
+            if g.shape != x.shape or g.dtype != dt or not g.is_contiguous():
+                raise L.MiqError("every gradient must be a contiguous tensor of its matrix's shape and dtype")
+
+
 def rowquant_uniform_fwd_batch(xs, n_bits: int, symmetric: bool, ups=None, lows=None, preactivated: bool = False):
     """Row-wise uniform fake quantization of several [O_i, I] matrices of one width and dtype in one launch.
     Returns (outs, scales, rzps) lists."""
     import ctypes
     lwc = ups is not None
     dev = L.check_gpu(*xs, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows)
     I = xs[0].shape[1]
-    for x in xs:
-        if x.dim() != 2 or x.shape[1] != I or x.dtype != xs[0].dtype or not x.is_contiguous():
-            raise L.MiqError("batched row quantization needs contiguous 2-D matrices of one width and dtype")
-    if len(xs) > 16:
-        raise L.MiqError("at most 16 matrices per batch")
     outs = [torch.empty_like(x) for x in xs]
     scales = [torch.empty((x.shape[0], 1), dtype=x.dtype, device=dev) for x in xs]
     rzps = [torch.empty_like(s) for s in scales]
@@ -109,6 +131,7 @@ def rowquant_uniform_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, l
     import ctypes
     lwc = ups is not None
     dev = L.check_gpu(*gs, *xs, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows, gs)
     I = xs[0].shape[1]
     dxs = [torch.empty_like(x) for x in xs] if want_dx else None
     d_ups = [torch.empty_like(u) for u in ups] if lwc else None

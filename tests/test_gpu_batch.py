@@ -64,3 +64,29 @@ def test_batch_autograd_function():
         assert torch.equal(a, b)
     with pytest.raises(Exception):
         F.rowquant_uniform_fwd_batch([xs[0].detach(), torch.zeros(4, 128, device=DEV)], 4, False)
+
+
+def test_batch_wrappers_refuse_what_the_kernels_cannot_check():
+    """The batched kernels walk raw pointer tables: mis-sized factors, gradients of another shape or dtype, missing
+    entries and more than 16 matrices must fail in the wrapper, not read or write out of bounds on the device."""
+    from miq._lib import MiqError
+    xs = [synth.weight(r, 64, 3 + i).to(DEV) for i, r in enumerate((8, 16))]
+    ups = [torch.full((x.shape[0], 1), 4.0, device=DEV) for x in xs]
+    lows = [torch.full((x.shape[0], 1), 4.0, device=DEV) for x in xs]
+    gs = [torch.randn_like(x) for x in xs]
+    F.rowquant_uniform_fwd_batch(xs, 4, False, ups, lows)
+    F.rowquant_uniform_bwd_batch(gs, xs, 4, False, ups, lows)
+    bad = [
+        lambda: F.rowquant_uniform_fwd_batch(xs, 4, False, ups[:1], lows),             # one factor missing
+        lambda: F.rowquant_uniform_fwd_batch(xs, 4, False, [ups[0], ups[0]], lows),    # 8 factors for 16 rows
+        lambda: F.rowquant_uniform_fwd_batch(xs, 4, False, [u.half() for u in ups], lows),
+        lambda: F.rowquant_uniform_fwd_batch(xs, 4, False, ups, None),
+        lambda: F.rowquant_uniform_fwd_batch(xs * 9, 4, False),                        # 18 matrices
+        lambda: F.rowquant_uniform_bwd_batch(gs[:1], xs, 4, False, ups, lows),
+        lambda: F.rowquant_uniform_bwd_batch([gs[0], gs[0]], xs, 4, False, ups, lows),  # gradient of another shape
+        lambda: F.rowquant_uniform_bwd_batch([g.half() for g in gs], xs, 4, False, ups, lows),
+        lambda: F.rowquant_uniform_bwd_batch(gs * 9, xs * 9, 4, False),
+    ]
+    for i, fn in enumerate(bad):
+        with pytest.raises(MiqError):
+            fn()

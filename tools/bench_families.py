@@ -87,6 +87,35 @@ def main():
                lambda x, g, u, l: F.rowquant_uniform_fwd(x, 3, False, u, l),
                lambda x, g, u, l: F.rowquant_uniform_bwd(g, x, 3, False, u, l, want_dx=True), res,
                lambda x, g, u, l: F.rowquant_uniform_bwd(g, x, 3, False, u, l, want_dx=False))
+    # the same six matrices through the batched entry points: one launch per row width instead of one per matrix
+    def c1_batched():
+        es = 4
+        sets = weights(OPT125, f32, copies_for(OPT125, es))
+        n = sum(o * i for o, i in OPT125) * es * len(sets)
+        groups = {}
+        for j, (_o, i) in enumerate(OPT125):
+            groups.setdefault(i, []).append(j)
+
+        def fwd():
+            for st in sets:
+                for ids in groups.values():
+                    F.rowquant_uniform_fwd_batch([st[j][0] for j in ids], 3, False, [st[j][2] for j in ids], [st[j][3] for j in ids])
+
+        def bwd():
+            for st in sets:
+                for ids in groups.values():
+                    F.rowquant_uniform_bwd_batch([st[j][1] for j in ids], [st[j][0] for j in ids], 3, False, [st[j][2] for j in ids],
+                                                 [st[j][3] for j in ids])
+
+        for tag, fn, mult in (("fwd", fwd, 2), ("bwd", bwd, 3)):
+            t = time_graph(fn)
+            gbs = mult * n / t / 1e9
+            res[f"C1.uniform_w3_lwc.opt125m.batched.{tag}.f32"] = {"GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK, 4),
+                                                                  "us_per_matrix_set": round(t / len(sets) * 1e6, 1)}
+        del sets
+        torch.cuda.empty_cache()
+
+    c1_batched()
     # uniform on 7B shapes (the weights of C2)
     for dt in (f32, f16):
         row_family("C2.uniform_w4_lwc.llama7b", L7, dt,
