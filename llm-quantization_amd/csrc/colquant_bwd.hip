@@ -113,7 +113,7 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
     // flight (a chunk is typically 32 rows: one or two batches per wave).  The first batch is issued before the per-channel parameters are fetched.
     // 32 elements per batch keep the kernel under 128 registers (four waves per SIMD) without spills; larger
     // batches were measured: no faster in fp32, slower in fp16
-    constexpr int UNR = VEC == 8 ? 2 : 4;
+    constexpr int UNR = VEC == 8 ? 2 : 4;  // (fp16 with 4 rows, retried with the one-parameter-set form: 64 bytes of spills, 3 % slower)
     Pack<T, VEC> a[UNR], b[UNR];
     auto load_batch = [&](long long r) {
 #pragma unroll
@@ -147,6 +147,10 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
     auto stream_rows = [&](auto exact_tag, auto nan_tag) {
         constexpr bool EX = decltype(exact_tag)::value;
         constexpr bool NANS = decltype(nan_tag)::value;
+        // Ties with the extremes are rare: per element only a running maximum / minimum of the batch is kept (the
+        // hardware's three-operand forms: one operation per element for both), and the elements are compared and
+        // counted one by one only in a wave whose batch reaches an extreme.
+        float bmx[NP], bmn[NP];
         auto body = [&](const Pack<T, VEC>& pa, const Pack<T, VEC>& pb, long long r) {
             Pack<T, VEC> o;
 #pragma unroll
@@ -162,8 +166,8 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
                 if (!EX) xd = rnd<T>(xd);
                 // outside the grid the quotient drops out; rq - rq is 0, or NaN when the level is NaN
                 acc[e] += gv * (xd - (m ? q : rq - rq));
-                nmx[e] += (xv == cmx[k]) ? 1 : 0;
-                nmn[e] += (xv == cmn[k]) ? 1 : 0;
+                bmx[k] = __builtin_fmaxf(bmx[k], xv);
+                bmn[k] = __builtin_fminf(bmn[k], xv);
                 o.e[e] = direct_out<T>(pb.e[e], gv, s[k], rs[k], m, NANS ? from_f<T>(0.f / s[k]) : from_f<T>(0.f));
             }
             st_pack<T, VEC>(dx + r * C + col0, o);
@@ -172,8 +176,27 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
         // it, the register pressure: measured 2x slower)
         for (long long r = r0 + w; r < r1;) {
 #pragma unroll
+            for (int k = 0; k < NP; ++k) { bmx[k] = -__builtin_inff(); bmn[k] = __builtin_inff(); }
+#pragma unroll
             for (int u = 0; u < UNR; ++u)
                 if (r + 4 * u < r1) body(a[u], b[u], r + 4 * u);
+            bool tie = false;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) tie = tie || bmx[k] == cmx[k] || bmn[k] == cmn[k];
+            if (__any(tie)) {
+                // (the rows are read again, from cache, rather than kept in registers for a case this rare)
+#pragma unroll 1
+                for (int u = 0; u < UNR; ++u) {
+                    if (r + 4 * u >= r1) break;
+                    const Pack<T, VEC> again = ld_pack<T, VEC>(x + (r + 4 * u) * C + col0);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float xv = to_f<T>(again.e[e]);
+                        nmx[e] += (xv == cmx[UNIFORM ? 0 : e]) ? 1 : 0;
+                        nmn[e] += (xv == cmn[UNIFORM ? 0 : e]) ? 1 : 0;
+                    }
+                }
+            }
             r += 4 * UNR;
             if (r < r1) load_batch(r);
         }
