@@ -28,4 +28,17 @@ echo "[collect] fused-operator A/B"; timeout -k 10 300 python3 -u tools/ab_block
 cd /tmp
 echo "[collect] block step trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/block7b" -- python3 "$R/tools/bench_block.py" --model 7b --amp > "$D/block7b.log" 2>&1
+echo "[collect] SQ counters (row quantizers, bench kernels)"
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
+timeout -s KILL 120 rocprofv3 --pmc $SQ --output-format csv -d "$D/sq_rows" -- python3 "$R/tools/row_pmc.py" > "$D/sq_rows.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc $SQ --output-format csv -d "$D/sq_bench" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib > "$D/sq_bench.log" 2>&1
+cd "$R"
+python3 tools/row_pmc_summary.py "$D"/sq_rows/*/*counter_collection.csv "$D/sq_rows.json" > /dev/null
+python3 tools/row_pmc_summary.py "$D"/sq_bench/*/*counter_collection.csv "$D/sq_bench.json" > /dev/null
+echo "[collect] row-sharded workload, one GPU"; timeout -k 10 300 python3 -u bench.py --workload c4 --steps 10 --warmup 3 > "$D/bench_c4.json.log" 2> "$D/bench_c4.err"
+echo "[collect] norm + quantizer, separate against fused"; timeout -k 10 120 python3 -u tools/dev/norm_quant_time.py > "$D/norm_quant_time.txt" 2>&1
+echo "[collect] micro-benchmarks"
+for b in actbench readbw statbench; do
+    if [ -x tools/ubench/$b ]; then timeout -k 10 120 tools/ubench/$b > "$D/ubench_$b.txt" 2>&1; fi
+done
 echo "[collect] done"

@@ -25,6 +25,15 @@ def main():
     extra = os.path.join(src, "blocks_extra.jsonl")
     if os.path.exists(extra):
         shutil.copy(extra, os.path.join(prof, f"{tag}_blocks_extra.jsonl"))
+    for name, dst in (("sq_rows.json", "sq_rows.json"), ("sq_bench.json", "sq_bench.json"), ("bench_c4.json.log", "bench_c4.json.log"),
+                      ("norm_quant_time.txt", "norm_quant_time.txt"), ("ubench_actbench.txt", "ubench_actbench.txt"),
+                      ("ubench_readbw.txt", "ubench_readbw.txt"), ("ubench_statbench.txt", "ubench_statbench.txt"),
+                      ("ab_block.json", "ab_block.json")):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(prof, f"{tag}_{dst}"))
+    b7 = glob.glob(os.path.join(src, "block7b", "*", "*kernel_stats.csv"))
+    if b7:
+        shutil.copy(b7[0], os.path.join(prof, f"{tag}_block7b_kernel_stats.csv"))
     paths = {}
     for name in ("fetch", "write"):
         path = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))[0]
