@@ -55,6 +55,11 @@ class CalibConfig:
     aug_loss: bool = False                 # add the MSE against the fp block applied to the QUANTIZED model's inputs
     fused_adamw: bool = False              # torch's fused AdamW: no host synchronisation in GradScaler.step, but its
                                            # arithmetic differs in the last bits from the default implementation
+    graph_step: bool = False               # replay forward + loss + backward of a step from one HIP graph (captured after
+                                           # the first, eager step; the optimizer stays eager).  Same kernels on the same
+                                           # data: the trajectory is that of the eager loop.  Single process, fixed batch
+                                           # shape, not with weight_mix_quant (its phases change the step)
+    graph_check_every: int = 64            # with graph_step: every so many steps one step is also run eagerly and compared
     autocast_passes: bool = True           # run the full-precision target pass and the final propagation pass under fp16
                                            # autocast whatever deactive_amp says, as the reference does
                                            # (quantize/omniquant.py:402, :583); False keeps them in the training precision
@@ -333,6 +338,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
 
     losses: List[float] = []
     norms: List[float] = []
+    graph_steps = 0
     if cfg.epochs > 0:
         with torch.no_grad():
             qlayer.float()
@@ -360,9 +366,9 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
             with traincast():
                 qlayer.smooth_and_quant_temporary()
                 out = qlayer(xb, attention_mask=mask_batch, position_ids=position_ids)[0]
-                loss = loss_func(yb, out)
+                loss = loss_func(yb, out, kernel=want_graph)
                 if cfg.aug_loss:
-                    loss = loss + loss_func(yb2, out)
+                    loss = loss + loss_func(yb2, out, kernel=want_graph)
                 if cfg.weight_mix_quant:
                     ms, ts = qlayer.get_size_loss()
                     loss = loss + loss_func(ms, ts) * loss_size_coef
@@ -375,6 +381,63 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
             return quant_inps[sl], fp_inps[sl], (fp_inps_2[sl] if cfg.aug_loss else None)
 
         omni_params = list(qlayer.omni_parameters(cfg.use_shift))  # one walk of the module tree, not one per step
+        # A step replayed from a HIP graph: the first step runs eagerly (it warms every lazily built piece of state), then
+        # forward + loss + backward are captured ONCE with empty gradients and freed activation statistics, reading the
+        # batch from static buffers; every later step copies its batch in, replays, and runs the optimizer eagerly on the
+        # gradient tensors the capture created (they are never set to None again: the next replay overwrites them).
+        want_graph = (cfg.graph_step and dev.type == "cuda" and not dp.active and not cfg.weight_mix_quant
+                      and steps_per_epoch * cfg.epochs > 2)
+        graph = static = None
+        # the eager first step runs on the stream the capture will use: workspaces and library handles are per stream
+        side = torch.cuda.Stream(device=dev) if want_graph else None
+
+        def capture_step():
+            xb, yb, yb2 = batch(0)
+            st = (torch.empty_like(xb), torch.empty_like(yb), torch.empty_like(yb2) if yb2 is not None else None)
+            optimizer.zero_grad(set_to_none=True)
+            _free_act_stats(qlayer)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                loss_static = forward_backward(*st)
+            _free_act_stats(qlayer)  # (the capture ran the Python side of a forward pass)
+            return g, st + (loss_static,)
+
+        def replay_step(j):
+            xb, yb, yb2 = batch(j)
+            static[0].copy_(xb)
+            static[1].copy_(yb)
+            if yb2 is not None:
+                static[2].copy_(yb2)
+            graph.replay()
+            return static[3]
+
+        # The first replayed steps, and one step in every cfg.graph_check_every afterwards, are ALSO run eagerly (the
+        # optimizer consumes the eager gradients) and compared bit for bit with a replay that follows another replay:
+        # PyTorch's multi-block reductions (full sums / means / norms, column sums) do not survive HIP-graph replay on every
+        # ROCm build (stale or garbage results when a replay follows a replay; no kernel of this library is involved), and a
+        # block variant that still routes one through ATen must fall back to the eager loop rather than train on it.
+        verified = [0]
+        graph_steps = 0
+
+        def checked_step(j):
+            static_grads = [p.grad for p in omni_params]
+            for p in omni_params:
+                p.grad = None
+            loss_e = forward_backward(*batch(j))
+            eager_grads = [p.grad for p in omni_params]
+            _free_act_stats(qlayer)
+            for p, g0 in zip(omni_params, static_grads):
+                p.grad = g0
+            replay_step(j)
+            loss_g = replay_step(j)  # the replay that is compared FOLLOWS a replay, like every later step does
+            same = torch.equal(loss_g, loss_e) and all(
+                (a is None and b is None) or (a is not None and b is not None and torch.equal(a, b))
+                for a, b in zip(static_grads, eager_grads))
+            for p, ge in zip(omni_params, eager_grads):
+                p.grad = ge  # this step's update uses the eager gradients either way
+            return loss_e, same, static_grads
+
+        done = 0
         for epoch in range(cfg.epochs):
             if cfg.weight_mix_quant:
                 if epoch == round(cfg.epochs * 0.5):
@@ -383,12 +446,41 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                     qlayer.round_nbits()
                     loss_size_coef = 0
             for j in range(steps_per_epoch):
-                optimizer.zero_grad()
-                loss = forward_backward(*batch(j))
+                if want_graph and done == 1 and graph is None:
+                    graph, static = capture_step()
+                restore = None
+                if graph is not None and (verified[0] < 2 or (cfg.graph_check_every and done % cfg.graph_check_every == 0)):
+                    loss, same, restore = checked_step(j)
+                    if same:
+                        verified[0] += 1
+                    elif verified[0] < 2:
+                        if logger is not None:
+                            logger.info(f"{layer_prefix}: the graph-replayed step differs from the eager step; continuing eagerly")
+                        graph = static = restore = None
+                        want_graph = False
+                    else:
+                        raise RuntimeError(f"{layer_prefix}: the graph-replayed step stopped reproducing the eager step at step "
+                                           f"{done}; rerun with graph_step=False")
+                elif graph is not None:
+                    loss = replay_step(j)
+                    graph_steps += 1
+                elif want_graph:
+                    optimizer.zero_grad()
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        loss = forward_backward(*batch(j))
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                else:
+                    optimizer.zero_grad()
+                    loss = forward_backward(*batch(j))
                 norm, buf = scaler.step(optimizer, omni_params, dp, buf)
+                if restore is not None:  # back to the gradient tensors the graph writes
+                    for p, g0 in zip(omni_params, restore):
+                        p.grad = g0
                 trace[0, j] = loss
                 trace[1, j] = norm
                 _free_act_stats(qlayer)
+                done += 1
             # one synchronisation per epoch: the reference tests the loss after every step
             # (omniquant.py:518-520); a non-finite loss only makes GradScaler skip that step, so the
             # delayed test sees the same parameters
@@ -404,12 +496,13 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
         qlayer.clear_temp_variable()
         optimizer.zero_grad(set_to_none=True)
         del optimizer
+        graph = static = None
     lap("train")
 
     finalize_layer(qlayer, quant_inps, attention_mask, cfg, dp, position_ids)
     lap("propagate")
     return {"losses": losses, "norms": norms, "indices": indices, "omni_state": qlayer.omni_state_dict(),
-            "seconds": seconds}
+            "seconds": seconds, "graph_steps": graph_steps}
 
 
 def finalize_layer(qlayer, quant_inps, attention_mask, cfg: CalibConfig, dp: Optional[DPContext] = None, position_ids=None):

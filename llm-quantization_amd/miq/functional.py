@@ -795,8 +795,9 @@ def mse_supported(a, b) -> bool:
 
 
 class MSELossHalf(torch.autograd.Function):
-    """torch.nn.functional.mse_loss(a, b) for fp16 tensors under autocast (which evaluates it in fp32): fp32 scalar
-    from one streaming pass over the fp16 tensors; gradients bit-identical to ATen's (miq_mse_fwd / miq_mse_bwd)."""
+    """torch.nn.functional.mse_loss(a, b) for fp16 tensors under autocast (which evaluates it in fp32) and for fp32
+    tensors: fp32 scalar from one streaming pass over the tensors; gradients bit-identical to ATen's (miq_mse_fwd /
+    miq_mse_bwd)."""
 
     @staticmethod
     def forward(ctx, a, b):
@@ -824,9 +825,13 @@ class MSELossHalf(torch.autograd.Function):
         return da, db
 
 
-def mse_loss(a, b):
-    """The calibration loss: MSELoss()(a, b) (reference quantize/omniquant.py:339, 511-513)."""
-    if mse_supported(a, b):
+def mse_loss(a, b, kernel=None):
+    """The calibration loss: MSELoss()(a, b) (reference quantize/omniquant.py:339, 511-513).  ``kernel=True`` takes the
+    kernel path for fp32 tensors too (same gradients bit for bit, the loss value in another summation order): a step
+    that is replayed from a HIP graph must not contain ATen's multi-block reduction."""
+    if mse_supported(a, b) or (kernel and a.is_cuda and b.is_cuda and a.dtype == b.dtype and a.shape == b.shape
+                               and a.dtype in (torch.float16, torch.float32) and a.numel() > 0
+                               and not (a.dtype == torch.float16 and not torch.is_autocast_enabled())):
         return MSELossHalf.apply(a, b)
     return torch.nn.functional.mse_loss(a, b)
 

@@ -43,6 +43,35 @@ def truncate_number(number, threshold=1e-2):
     return _Truncate.apply(number, threshold)
 
 
+class _MulColumns(torch.autograd.Function):
+    """w * c[None, :] for a 2-D weight and a per-column vector.  Autograd's own backward sums g * w over the rows with
+    ATen's multi-block reduction; here that column sum is the library's streaming kernel (fp32 partials, fixed-order
+    fold), which also keeps the step free of the one kind of ATen kernel that does not survive HIP-graph replay."""
+
+    @staticmethod
+    def forward(ctx, w, c):
+        ctx.save_for_backward(w, c)
+        return w * c.view(1, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import functional as F
+        w, c = ctx.saved_tensors
+        gw = g * c.view(1, -1) if ctx.needs_input_grad[0] else None
+        gc = None
+        if ctx.needs_input_grad[1]:
+            prod = (g * w).contiguous()
+            if prod.is_cuda and prod.dtype in (torch.float16, torch.float32) and prod.numel() > 0:
+                gc = F.col_sum(prod).to(c.dtype).view(c.shape)
+            else:
+                gc = prod.sum(0).view(c.shape)
+        return gw, gc
+
+
+def mul_columns(w, c):
+    return _MulColumns.apply(w, c) if w.dim() == 2 and c.numel() == w.shape[1] else w * c.view(1, -1)
+
+
 @dataclass
 class NormStep:
     """The norm emits (x - shift) / scale."""
@@ -78,7 +107,7 @@ class LinearStep:
     def weight(self):
         w = self.linear.weight
         if self.col_scale is not None:
-            w = w * self.col_scale.view(1, -1)
+            w = mul_columns(w, self.col_scale)
         if self.row_scale is not None:
             r = self.row_scale.view(-1, 1)
             w = w / r if self.row_div else w * r
