@@ -447,7 +447,15 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                     loss_size_coef = 0
             for j in range(steps_per_epoch):
                 if want_graph and done == 1 and graph is None:
-                    graph, static = capture_step()
+                    try:
+                        graph, static = capture_step()
+                    except RuntimeError as e:  # an operation that cannot be captured (a host synchronisation, say)
+                        if logger is not None:
+                            logger.info(f"{layer_prefix}: the step cannot be captured ({str(e)[:120]}); continuing eagerly")
+                        graph = static = None
+                        want_graph = False
+                        optimizer.zero_grad(set_to_none=True)
+                        _free_act_stats(qlayer)
                 restore = None
                 if graph is not None and (verified[0] < 2 or (cfg.graph_check_every and done % cfg.graph_check_every == 0)):
                     loss, same, restore = checked_step(j)
