@@ -367,12 +367,20 @@ int miq_row_absmean_accum(const void* g, float* acc, int64_t O, int64_t I, int d
  * floor either); div = sqrt(head_dim) for Llama, 1 for OPT (which scales q before the matmul).  x / div is
  * formed as x * (1/div) like ATen's tensor / scalar on a GPU and rounded to x's dtype.  C a multiple of 4 (fp32)
  * or 8 (fp16).
- * Backward: dx = p * (grad_out - sum_j grad_out_j p_j) / div from the saved probabilities.
+ * row_stats_out: NULL, or fp32 [R, 2] receiving each row's maximum and reciprocal sum of exponentials.
+ * Backward: dx = p * (grad_out - sum_j grad_out_j p_j) / div.  PyTorch's softmax(dtype=float32).to(fp16) keeps the
+ * fp32 probabilities for this, so there are two forms: miq_masked_softmax_bwd takes probabilities (exact for fp32
+ * scores, where `out` is that tensor); miq_masked_softmax_bwd_scores takes the forward's x, mask and row_stats
+ * and rebuilds the fp32 probabilities with the forward's own instructions (the form for fp16 scores: same
+ * traffic, no 2^-11 rounding of p in every gradient element).
  */
-int miq_masked_softmax_fwd(const void* x, const void* mask, void* out, int64_t R, int64_t C, int64_t rows_per_batch,
-                           int64_t q_len, float div, int x_dtype, int mask_dtype, void* stream);
+int miq_masked_softmax_fwd(const void* x, const void* mask, void* out, float* row_stats_out, int64_t R, int64_t C,
+                           int64_t rows_per_batch, int64_t q_len, float div, int x_dtype, int mask_dtype, void* stream);
 int miq_masked_softmax_bwd(const void* p, const void* grad_out, void* dx, int64_t R, int64_t C, float div, int dtype,
                            void* stream);
+int miq_masked_softmax_bwd_scores(const void* x, const void* mask, const float* row_stats, const void* grad_out, void* dx,
+                                  int64_t R, int64_t C, int64_t rows_per_batch, int64_t q_len, float div, int x_dtype,
+                                  int mask_dtype, void* stream);
 
 /*
  * OmniLlamaRMSNorm (quantize/omni_norm.py:60-71), the norm in front of the quantized q/k/v and up/gate

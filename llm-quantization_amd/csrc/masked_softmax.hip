@@ -12,9 +12,18 @@
 // reductions in fp32.  The summation order of
 // the softmax differs from ATen's, so probabilities agree to fp32 rounding, not bit for bit (these operators are
 // not quantizer arithmetic; the blocks' tests compare them with the PyTorch chain).
-// Backward from the saved probabilities p (output dtype) and the incoming gradient g:
+// Backward from the probabilities p and the incoming gradient g:
 //     dw = p * (g - sum_j g_j p_j) / sqrt(head_dim)
-// (positions cut by the max(., finfo.min) have p == 0, hence no gradient, like the reference's clamp mask).
+// (the softmax gradient is rounded to the scores' dtype before the division, as the reference's cast precedes its
+// division node)
+// (positions cut by the max(., finfo.min) have p == 0, hence no gradient, like the reference's clamp mask; a row whose
+// every key is masked has uniform p, and there ATen's maximum halves the gradient at w == finfo.min: the backward from
+// the scores reproduces that, the one from the probabilities cannot see it).
+// PyTorch keeps the fp32 softmax output for this, not the rounded copy it returns.  For fp32 scores the saved
+// output is that tensor.  For fp16 scores the forward also stores each row's fp32 maximum and reciprocal sum
+// (8 bytes a row), and the backward rebuilds the fp32 probabilities from the scores and the mask with the same
+// instructions as the forward (miq_masked_softmax_bwd_scores): the same traffic as reading the rounded
+// probabilities, without their 2^-11 relative error in every gradient element.
 #include "miq_common.h"
 
 namespace miq {
@@ -40,20 +49,10 @@ __device__ __forceinline__ long long mask_row(const SmArgs& a, long long row) {
     return (row / a.rows_per_batch) * a.q_len + row % a.q_len;
 }
 
+// v = x / div + mask of one row, with the roundings of the PyTorch chain; the caller applies the floor
 template <typename TX, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_masked_softmax_fwd(SmArgs a, TX* __restrict__ out) {
-    __shared__ float lds[32];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    // TEAM > 64 implies RPB == 1: a block is one row, so this exit is block-uniform where barriers follow
-    if (row >= a.R) return;
-    RowTile<TX, VEC, TEAM, NV> x;
-    x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
+__device__ __forceinline__ void masked_scores(const SmArgs& a, const RowTile<TX, VEC, TEAM, NV>& x, long long row, float (&v)[NV][VEC]) {
     const long long mrow = a.mask ? mask_row(a, row) : 0;
-    float v[NV][VEC];
-    float mx[1] = {-__builtin_inff()};
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
@@ -81,9 +80,32 @@ k_masked_softmax_fwd(SmArgs a, TX* __restrict__ out) {
                 t = t + mv[e];
                 if (a.sum_half) t = rnd<__half>(t);
             }
-            t = (t < a.floor_) ? a.floor_ : t;  // torch.max(w, finfo.min): NaN stays NaN
             v[k][e] = t;
-            mx[0] = nmax(mx[0], t);
+        }
+    }
+}
+
+template <typename TX, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_masked_softmax_fwd(SmArgs a, TX* __restrict__ out, float2* __restrict__ row_stats) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    // TEAM > 64 implies RPB == 1: a block is one row, so this exit is block-uniform where barriers follow
+    if (row >= a.R) return;
+    RowTile<TX, VEC, TEAM, NV> x;
+    x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
+    float v[NV][VEC];
+    masked_scores(a, x, row, v);
+    float mx[1] = {-__builtin_inff()};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[k][e] = (v[k][e] < a.floor_) ? a.floor_ : v[k][e];  // torch.max(w, finfo.min): NaN stays NaN
+            mx[0] = nmax(mx[0], v[k][e]);
         }
     }
     team_reduce<TEAM, 1>(mx, OpMaxNan(), lds);
@@ -99,6 +121,7 @@ k_masked_softmax_fwd(SmArgs a, TX* __restrict__ out) {
     }
     team_sum<TEAM, 1>(sum, lds);
     const float inv = 1.0f / sum[0];
+    if (row_stats && lane == 0) row_stats[row] = make_float2(mx[0], inv);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
@@ -136,21 +159,64 @@ k_masked_softmax_bwd(const TX* __restrict__ p, const TX* __restrict__ g, TX* __r
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float pv = to_f<TX>(pp.v[k].e[e]);
-            o.e[e] = from_f<TX>((pv * (to_f<TX>(gg.v[k].e[e]) - dot[0])) * inv_div);
+            o.e[e] = from_f<TX>(rnd<TX>(pv * (to_f<TX>(gg.v[k].e[e]) - dot[0])) * inv_div);
         }
         st_pack<TX, VEC>(dx + row * C + pp.offset(k), o);
     }
 }
 
+// The same from the scores: p = exp(w - max) * (1 / sum) in fp32 exactly as the forward formed it
+template <typename TX, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_masked_softmax_bwd_scores(SmArgs a, const float2* __restrict__ row_stats, const TX* __restrict__ g, TX* __restrict__ dx) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= a.R) return;
+    RowTile<TX, VEC, TEAM, NV> x, gg;
+    x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
+    gg.load_nt(g + row * a.C, a.C, lane);
+    const float2 st = row_stats[row];
+    float v[NV][VEC], pass[NV][VEC];
+    masked_scores(a, x, row, v);
+    float dot[1] = {0.f};
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            // gradient of torch.max(w, floor) with respect to w: 1 above the floor, 0 below, 1/2 on a tie (ATen's rule
+            // for maximum; it only shows in a row whose every key is masked, elsewhere p is 0 at the floor)
+            const float w = v[k][e];
+            pass[k][e] = (w < a.floor_) ? 0.f : (w == a.floor_ ? 0.5f : 1.f);
+            v[k][e] = __expf(((w < a.floor_) ? a.floor_ : w) - st.x) * st.y;
+            dot[0] += v[k][e] * to_f<TX>(gg.v[k].e[e]);
+        }
+    }
+    team_sum<TEAM, 1>(dot, lds);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+        Pack<TX, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float dw = rnd<TX>(v[k][e] * (to_f<TX>(gg.v[k].e[e]) - dot[0]));  // rounded by the softmax's cast
+            o.e[e] = from_f<TX>(rnd<TX>(dw * pass[k][e]) * a.inv_div);
+        }
+        st_pack<TX, VEC>(dx + row * a.C + x.offset(k), o);
+    }
+}
+
 template <typename TX>
-static int launch_sm_fwd(const SmArgs& a, void* out, hipStream_t stream) {
+static int launch_sm_fwd(const SmArgs& a, void* out, float* row_stats, hipStream_t stream) {
     constexpr int VEC = VecOf<TX>::N;
     const int npack = a.C / VEC;
 #define L(TEAM, NV)                                                                                               \
     {                                                                                                             \
         constexpr int RPB = block_of<TEAM>() / TEAM;                                                              \
         hipLaunchKernelGGL((k_masked_softmax_fwd<TX, VEC, TEAM, NV>), dim3((unsigned)((a.R + RPB - 1) / RPB)),    \
-                           dim3(block_of<TEAM>()), 0, stream, a, (TX*)out);                                       \
+                           dim3(block_of<TEAM>()), 0, stream, a, (TX*)out, (float2*)row_stats);                  \
     }
     MIQ_ROW_DISPATCH(npack, L);
 #undef L
@@ -174,31 +240,68 @@ static int launch_sm_bwd(const void* p, const void* g, void* dx, long long R, in
     return 0;
 }
 
+template <typename TX>
+static int launch_sm_bwd_scores(const SmArgs& a, const float* row_stats, const void* g, void* dx, hipStream_t stream) {
+    constexpr int VEC = VecOf<TX>::N;
+    const int npack = a.C / VEC;
+#define L(TEAM, NV)                                                                                                  \
+    {                                                                                                                \
+        constexpr int RPB = block_of<TEAM>() / TEAM;                                                                 \
+        hipLaunchKernelGGL((k_masked_softmax_bwd_scores<TX, VEC, TEAM, NV>), dim3((unsigned)((a.R + RPB - 1) / RPB)), \
+                           dim3(block_of<TEAM>()), 0, stream, a, (const float2*)row_stats, (const TX*)g, (TX*)dx);   \
+    }
+    MIQ_ROW_DISPATCH(npack, L);
+#undef L
+    MIQ_CHECK_LAUNCH("miq_masked_softmax_bwd_scores");
+    return 0;
+}
+
 }  // namespace miq
 
 using namespace miq;
 
-extern "C" int miq_masked_softmax_fwd(const void* x, const void* mask, void* out, int64_t R, int64_t C, int64_t rows_per_batch,
-                                      int64_t q_len, float div, int x_dtype, int mask_dtype, void* stream) {
-    if (R == 0 || C == 0) return 0;
-    MIQ_CHECK_ARG(x && out && R > 0 && C > 0, "miq_masked_softmax_fwd: null pointer or bad shape");
-    MIQ_CHECK_ARG(x_dtype == MIQ_F32 || x_dtype == MIQ_F16, "miq_masked_softmax_fwd: unsupported dtype %d", x_dtype);
+// argument checks and the kernel argument block shared by the forward and the backward from the scores
+static int sm_args(const char* who, const void* x, const void* mask, int64_t R, int64_t C, int64_t rows_per_batch, int64_t q_len,
+                   float div, int x_dtype, int mask_dtype, SmArgs& a) {
+    MIQ_CHECK_ARG(x && R > 0 && C > 0, "%s: null pointer or bad shape", who);
+    MIQ_CHECK_ARG(x_dtype == MIQ_F32 || x_dtype == MIQ_F16, "%s: unsupported dtype %d", who, x_dtype);
     const int vec = x_dtype == MIQ_F16 ? 8 : 4;
-    MIQ_CHECK_ARG(C % vec == 0 && C / vec <= kRowMaxPacks && C < (1ll << 31),
-                  "miq_masked_softmax_fwd: C=%lld must be a multiple of %d and at most %d", (long long)C, vec, vec * kRowMaxPacks);
-    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(out) && is_aligned16(mask), "miq_masked_softmax_fwd: pointers must be 16-byte aligned");
+    MIQ_CHECK_ARG(C % vec == 0 && C / vec <= kRowMaxPacks && C < (1ll << 31), "%s: C=%lld must be a multiple of %d and at most %d", who,
+                  (long long)C, vec, vec * kRowMaxPacks);
+    MIQ_CHECK_ARG(is_aligned16(x) && is_aligned16(mask), "%s: pointers must be 16-byte aligned", who);
     MIQ_CHECK_ARG(!mask || ((mask_dtype == MIQ_F32 || mask_dtype == MIQ_F16) && q_len > 0 && rows_per_batch > 0 &&
                             rows_per_batch % q_len == 0 && R % rows_per_batch == 0),
-                  "miq_masked_softmax_fwd: mask needs q_len > 0 and rows_per_batch (a multiple of q_len) dividing R");
-    MIQ_CHECK_ARG(div > 0.f, "miq_masked_softmax_fwd: divisor must be positive");
-    SmArgs a;
+                  "%s: mask needs q_len > 0 and rows_per_batch (a multiple of q_len) dividing R", who);
+    MIQ_CHECK_ARG(div > 0.f, "%s: divisor must be positive", who);
     a.x = x; a.mask = mask; a.mask_half = mask_dtype == MIQ_F16;
     a.sum_half = (x_dtype == MIQ_F16 && mask_dtype == MIQ_F16);
     a.inv_div = 1.0f / div;
     a.floor_ = !mask ? -__builtin_inff() : (a.sum_half ? -65504.0f : -3.4028234663852886e38f);
     a.R = R; a.C = (int)C; a.rows_per_batch = mask ? rows_per_batch : 1; a.q_len = mask ? (int)q_len : 1;
-    if (x_dtype == MIQ_F32) return launch_sm_fwd<float>(a, out, (hipStream_t)stream);
-    return launch_sm_fwd<__half>(a, out, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int miq_masked_softmax_fwd(const void* x, const void* mask, void* out, float* row_stats_out, int64_t R, int64_t C,
+                                      int64_t rows_per_batch, int64_t q_len, float div, int x_dtype, int mask_dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    SmArgs a;
+    if (const int rc = sm_args("miq_masked_softmax_fwd", x, mask, R, C, rows_per_batch, q_len, div, x_dtype, mask_dtype, a)) return rc;
+    MIQ_CHECK_ARG(out && is_aligned16(out) && (reinterpret_cast<uintptr_t>(row_stats_out) & 7) == 0,
+                  "miq_masked_softmax_fwd: out must be 16-byte aligned, row_stats_out 8-byte aligned");
+    if (x_dtype == MIQ_F32) return launch_sm_fwd<float>(a, out, row_stats_out, (hipStream_t)stream);
+    return launch_sm_fwd<__half>(a, out, row_stats_out, (hipStream_t)stream);
+}
+
+extern "C" int miq_masked_softmax_bwd_scores(const void* x, const void* mask, const float* row_stats, const void* grad_out, void* dx,
+                                             int64_t R, int64_t C, int64_t rows_per_batch, int64_t q_len, float div, int x_dtype,
+                                             int mask_dtype, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    SmArgs a;
+    if (const int rc = sm_args("miq_masked_softmax_bwd_scores", x, mask, R, C, rows_per_batch, q_len, div, x_dtype, mask_dtype, a)) return rc;
+    MIQ_CHECK_ARG(row_stats && grad_out && dx && is_aligned16(grad_out) && is_aligned16(dx) && (reinterpret_cast<uintptr_t>(row_stats) & 7) == 0,
+                  "miq_masked_softmax_bwd_scores: null pointer, or grad_out / dx not 16-byte aligned, or row_stats not 8-byte aligned");
+    if (x_dtype == MIQ_F32) return launch_sm_bwd_scores<float>(a, row_stats, grad_out, dx, (hipStream_t)stream);
+    return launch_sm_bwd_scores<__half>(a, row_stats, grad_out, dx, (hipStream_t)stream);
 }
 
 extern "C" int miq_masked_softmax_bwd(const void* p, const void* grad_out, void* dx, int64_t R, int64_t C, float div, int dtype,

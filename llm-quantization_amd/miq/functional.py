@@ -589,7 +589,9 @@ def masked_softmax_supported(scores, mask) -> bool:
 
 class MaskedSoftmax(torch.autograd.Function):
     """softmax(max(scores / div + mask, finfo.min), dim=-1, dtype=float32).to(scores.dtype) for [B, H, Q, K]
-    scores and a [B or 1, 1, Q, K] mask (or None), one kernel per direction (miq_masked_softmax_fwd / _bwd)."""
+    scores and a [B or 1, 1, Q, K] mask (or None), one kernel per direction.  The reference's backward uses the fp32
+    probabilities, not the rounded output: the backward rebuilds them from the scores, the mask and the forward's per-row
+    maximum and reciprocal sum (miq_masked_softmax_bwd_scores)."""
 
     @staticmethod
     def forward(ctx, scores, mask, div):
@@ -600,22 +602,27 @@ class MaskedSoftmax(torch.autograd.Function):
         if mask is not None:
             m = mask.expand(B, 1, Q, K).contiguous() if mask.shape[0] != B and B > 1 else mask.contiguous()
         dev = L.check_gpu(x, m)
+        need = ctx.needs_input_grad[0]
+        stats = torch.empty((B * H * Q, 2), dtype=torch.float32, device=x.device) if need else None
         with L.on_device(dev):
-            L.call("miq_masked_softmax_fwd", L.ptr(x), L.ptr(m), L.ptr(out), L.i64(B * H * Q), L.i64(K), L.i64(H * Q), L.i64(Q),
-                   L.f32(float(div)), L.i32(L.dtype_code(x)), L.i32(L.dtype_code(m) if m is not None else L.F32), L.stream_of(x))
-        ctx.save_for_backward(out)
+            L.call("miq_masked_softmax_fwd", L.ptr(x), L.ptr(m), L.ptr(out), L.ptr(stats), L.i64(B * H * Q), L.i64(K), L.i64(H * Q),
+                   L.i64(Q), L.f32(float(div)), L.i32(L.dtype_code(x)), L.i32(L.dtype_code(m) if m is not None else L.F32),
+                   L.stream_of(x))
+        if need:
+            ctx.save_for_backward(x, m, stats)
         ctx.div = float(div)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (p,) = ctx.saved_tensors
         g = g.contiguous()
-        dx = torch.empty_like(p)
-        K = p.shape[-1]
-        with L.on_device(p.device):
-            L.call("miq_masked_softmax_bwd", L.ptr(p), L.ptr(g), L.ptr(dx), L.i64(p.numel() // K), L.i64(K), L.f32(ctx.div),
-                   L.i32(L.dtype_code(p)), L.stream_of(p))
+        x, m, stats = ctx.saved_tensors
+        B, H, Q, K = x.shape
+        dx = torch.empty_like(x)
+        with L.on_device(x.device):
+            L.call("miq_masked_softmax_bwd_scores", L.ptr(x), L.ptr(m), L.ptr(stats), L.ptr(g), L.ptr(dx), L.i64(B * H * Q),
+                   L.i64(K), L.i64(H * Q), L.i64(Q), L.f32(ctx.div), L.i32(L.dtype_code(x)),
+                   L.i32(L.dtype_code(m) if m is not None else L.F32), L.stream_of(x))
         return dx, None, None
 
 

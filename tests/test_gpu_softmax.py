@@ -17,7 +17,7 @@ def chain(scores, mask, div):
     w = scores / div if div != 1.0 else scores
     if mask is not None:
         w = w + mask
-        w = w.clamp(min=torch.finfo(w.dtype).min)
+        w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min))  # the reference's form: ties pass half the gradient
     return TF.softmax(w, dim=-1, dtype=torch.float32).to(scores.dtype)
 
 
@@ -57,9 +57,41 @@ def test_forward_and_backward_match_the_pytorch_chain(B, H, Q, K, dt, mdt, mb, d
     (dx,) = torch.autograd.grad(out, xs, go)
     (dr,) = torch.autograd.grad(ref, xr, go)
     err = (dx.float() - dr.float()).norm() / dr.float().norm().clamp_min(1e-20)
-    assert err.item() <= (3e-3 if dt == torch.float16 else 1e-5), err.item()
-    fully_masked = out == 0
-    assert torch.all(dx[fully_masked] == 0)
+    # both sides hold fp32 probabilities in the backward (for fp16 scores ours are rebuilt from the scores): what is left is
+    # the rounding of the result to the scores' dtype where the two fp32 values straddle a rounding boundary
+    assert err.item() <= (2e-4 if dt == torch.float16 else 1e-5), err.item()
+    if mask is not None:
+        # masked positions carry no gradient (probabilities that merely round to 0 in fp16 do, as in PyTorch; so do the
+        # uniform probabilities of a row whose every key is masked)
+        cut = (mask == torch.finfo(mdt).min).expand(B, 1, Q, K).expand(B, H, Q, K) & (out == 0)
+        assert torch.all(dx[cut] == 0)
+
+
+def test_fp16_backward_from_scores_beats_the_one_from_rounded_probabilities():
+    """The reference keeps the fp32 softmax output for its backward.  The backward that rebuilds the fp32 probabilities
+    (the one the autograd function uses for fp16 scores) is compared with the one that reads the rounded output, both
+    against the gradient of the PyTorch chain itself, element for element."""
+    from miq import _lib as L
+    B, H, Q, K = 1, 8, 256, 512
+    div = math.sqrt(128.0)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    scores = (torch.randn(B, H, Q, K, generator=g, device=DEV) * 4).half()
+    mask = torch.full((Q, K), torch.finfo(torch.float32).min, device=DEV).triu(1 + K - Q).view(1, 1, Q, K)
+    go = torch.randn(B, H, Q, K, generator=g, device=DEV).half()
+    xs = scores.clone().requires_grad_(True)
+    out = F.MaskedSoftmax.apply(xs, mask, div)
+    (dx,) = torch.autograd.grad(out, xs, go)
+    dp = torch.empty_like(out)
+    with L.on_device(out.device):
+        L.call("miq_masked_softmax_bwd", L.ptr(out.detach()), L.ptr(go), L.ptr(dp), L.i64(B * H * Q), L.i64(K), L.f32(div),
+               L.i32(L.dtype_code(out)), L.stream_of(out))
+    xr = scores.clone().requires_grad_(True)
+    (dr,) = torch.autograd.grad(chain(xr, mask, div), xr, go)
+    same_scores = (dx == dr).float().mean().item()
+    same_probs = (dp == dr).float().mean().item()
+    print(f"bit-equal to the PyTorch chain's gradient: from scores {same_scores:.4f}, from rounded probabilities {same_probs:.4f}")
+    assert same_scores >= 0.999, same_scores   # summation order of the softmax and of the dot product differ
+    assert same_probs < same_scores
 
 
 def test_rows_sum_to_one_at_block_size():
