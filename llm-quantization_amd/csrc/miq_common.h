@@ -161,11 +161,28 @@ struct LevelDivisor {
     __device__ __forceinline__ explicit LevelDivisor(float s_) : s(s_), rs(1.0f / s_) {}
     __device__ __forceinline__ float div(float x) const { return level_div(x, s, rs); }
 };
-// divisor types of the arithmetic-bound row kernels
-template <typename T> struct BwdDivisorOf { using type = Divisor<T>; };
+// fp16 quotient for a divisor that is finite and not zero, or NaN (half_div_ok; a calibrated scale clamped to
+// [1e-5, 1e4] always is): the corrected product of Divisor<__half> below without its per-element test.  The test is a
+// property of the row, and left inside the element loop the compiler keeps both forms behind a branch per element.
+struct HalfDivisor {
+    float s, rs;
+    __device__ __forceinline__ explicit HalfDivisor(float s_) : s(s_), rs(1.0f / s_) {}
+    __device__ __forceinline__ float div(float x) const {
+        const float q0 = x * rs;
+        return __half2float(__float2half(__builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0)));
+    }
+};
+__device__ __forceinline__ bool half_div_ok(float s) {
+    const float a = fabsf(s);
+    return !((a == 0.f) || (a == __builtin_inff()));
+}
+// divisor types of the arithmetic-bound row kernels (their scales are clamped)
+template <typename T> struct BwdDivisorOf;
 template <> struct BwdDivisorOf<float> { using type = UncheckedDivisor; };
-template <typename T> struct FastDivisorOf { using type = Divisor<T>; };
+template <> struct BwdDivisorOf<__half> { using type = HalfDivisor; };
+template <typename T> struct FastDivisorOf;
 template <> struct FastDivisorOf<float> { using type = CorrectedDivisor; };
+template <> struct FastDivisorOf<__half> { using type = HalfDivisor; };
 template <> struct Divisor<__half> {
     float s, rs;
     bool fast;
@@ -422,16 +439,29 @@ __device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, l
 // Teams that are not powers of two (384 x 8 for 11008-wide rows, 320 x 4, 448 x 8, 896 x 8) remove the idle
 // lanes of the next larger tile but were measured slower in the backward kernels (6 or 7 waves per block
 // spread unevenly over the 4 SIMDs), so the table stays with power-of-two teams.
-#define MIQ_ROW_DISPATCH(NPACK, LAUNCH)                                  \
+// ESZ == 2 selects tiles with half the packs per lane on twice the lanes beyond 512 packs: a 2-byte pack carries 8
+// elements, and 32 to 64 elements per lane cost the register-hungry fp16 kernels (the exponent grids' backward: 190 to
+// 270 registers) their occupancy.  The light kernels (uniform grids) are faster on the ESZ == 4 table in fp16 as well
+// (1024-thread blocks and their block-wide reductions cost them 5 to 25 %), so every caller names the table it wants.
+#define MIQ_ROW_DISPATCH_E(ESZ, NPACK, LAUNCH)                           \
     do {                                                                 \
         if ((NPACK) <= 16) { LAUNCH(16, 1); }                            \
         else if ((NPACK) <= 64) { LAUNCH(16, 4); }                       \
         else if ((NPACK) <= 256) { LAUNCH(64, 4); }                      \
-        else if ((NPACK) <= 1024) { LAUNCH(256, 4); }                    \
-        else if ((NPACK) <= 2048) { LAUNCH(256, 8); }                    \
-        else if ((NPACK) <= 4096) { LAUNCH(512, 8); }                    \
-        else { LAUNCH(1024, 8); }                                        \
+        else if ((NPACK) <= 512) { LAUNCH(256, 2); }                     \
+        else if constexpr ((ESZ) == 2) {                                 \
+            if ((NPACK) <= 1024) { LAUNCH(512, 2); }                     \
+            else if ((NPACK) <= 2048) { LAUNCH(1024, 2); }               \
+            else if ((NPACK) <= 4096) { LAUNCH(1024, 4); }               \
+            else { LAUNCH(1024, 8); }                                    \
+        } else {                                                         \
+            if ((NPACK) <= 1024) { LAUNCH(256, 4); }                     \
+            else if ((NPACK) <= 2048) { LAUNCH(256, 8); }                \
+            else if ((NPACK) <= 4096) { LAUNCH(512, 8); }                \
+            else { LAUNCH(1024, 8); }                                    \
+        }                                                                \
     } while (0)
+#define MIQ_ROW_DISPATCH(NPACK, LAUNCH) MIQ_ROW_DISPATCH_E(4, NPACK, LAUNCH)
 
 // Launch KERN<T, VEC, TEAM, NV> over all rows of GEO with the (TEAM, NV) that fits NPACK packs per row.
 #define MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, TEAM, NV, GEO, STREAM, ...)                                        \
@@ -440,24 +470,36 @@ __device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, l
         const long long nb_ = ((GEO).n_rows + (B_ / TEAM) - 1) / (B_ / TEAM);                                \
         hipLaunchKernelGGL((KERN<T, VECN, TEAM, NV>), dim3((unsigned)nb_), dim3(B_), 0, STREAM, __VA_ARGS__); \
     }
-#define MIQ_ROW_LAUNCH_VEC(KERN, T, VECN, NPACK, GEO, STREAM, ...)                                   \
-    do {                                                                                             \
-        if ((NPACK) <= 16) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 16, 1, GEO, STREAM, __VA_ARGS__)        \
-        else if ((NPACK) <= 64) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 16, 4, GEO, STREAM, __VA_ARGS__)   \
-        else if ((NPACK) <= 256) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 64, 4, GEO, STREAM, __VA_ARGS__)  \
-        else if ((NPACK) <= 1024) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 4, GEO, STREAM, __VA_ARGS__) \
-        else if ((NPACK) <= 2048) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 8, GEO, STREAM, __VA_ARGS__) \
-        else if ((NPACK) <= 4096) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 8, GEO, STREAM, __VA_ARGS__) \
-        else MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 8, GEO, STREAM, __VA_ARGS__)                    \
+#define MIQ_ROW_LAUNCH_VEC(ESZ, KERN, T, VECN, NPACK, GEO, STREAM, ...)                                         \
+    do {                                                                                                   \
+        if ((NPACK) <= 16) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 16, 1, GEO, STREAM, __VA_ARGS__)              \
+        else if ((NPACK) <= 64) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 16, 4, GEO, STREAM, __VA_ARGS__)         \
+        else if ((NPACK) <= 256) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 64, 4, GEO, STREAM, __VA_ARGS__)        \
+        else if ((NPACK) <= 512) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 2, GEO, STREAM, __VA_ARGS__)       \
+        else if constexpr ((ESZ) == 2) {                                                                     \
+            if ((NPACK) <= 1024) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 2, GEO, STREAM, __VA_ARGS__)       \
+            else if ((NPACK) <= 2048) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 2, GEO, STREAM, __VA_ARGS__) \
+            else if ((NPACK) <= 4096) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 4, GEO, STREAM, __VA_ARGS__) \
+            else MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 8, GEO, STREAM, __VA_ARGS__)                      \
+        } else {                                                                                           \
+            if ((NPACK) <= 1024) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 4, GEO, STREAM, __VA_ARGS__)       \
+            else if ((NPACK) <= 2048) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 8, GEO, STREAM, __VA_ARGS__)  \
+            else if ((NPACK) <= 4096) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 8, GEO, STREAM, __VA_ARGS__)  \
+            else MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 8, GEO, STREAM, __VA_ARGS__)                      \
+        }                                                                                                  \
     } while (0)
-#define MIQ_ROW_LAUNCH(KERN, T, VEC_OK, GEO, STREAM, ...)                                            \
+#define MIQ_ROW_LAUNCH_E(ESZ, KERN, T, VEC_OK, GEO, STREAM, ...)                                     \
     do {                                                                                             \
         if (VEC_OK) {                                                                                \
-            MIQ_ROW_LAUNCH_VEC(KERN, T, miq::VecOf<T>::N, (GEO).g / miq::VecOf<T>::N, GEO, STREAM, __VA_ARGS__); \
+            MIQ_ROW_LAUNCH_VEC(ESZ, KERN, T, miq::VecOf<T>::N, (GEO).g / miq::VecOf<T>::N, GEO, STREAM, __VA_ARGS__); \
         } else {                                                                                     \
-            MIQ_ROW_LAUNCH_VEC(KERN, T, 1, (GEO).g, GEO, STREAM, __VA_ARGS__);                       \
+            MIQ_ROW_LAUNCH_VEC(ESZ, KERN, T, 1, (GEO).g, GEO, STREAM, __VA_ARGS__);                  \
         }                                                                                            \
     } while (0)
+// the table of 4-byte elements for every element size (the light kernels are fastest on it in fp16 too)
+#define MIQ_ROW_LAUNCH(KERN, T, VEC_OK, GEO, STREAM, ...) MIQ_ROW_LAUNCH_E(4, KERN, T, VEC_OK, GEO, STREAM, __VA_ARGS__)
+// the table of the element's own size: for kernels that hold many registers per element (the exponent grids' backward)
+#define MIQ_ROW_LAUNCH_SIZED(KERN, T, VEC_OK, GEO, STREAM, ...) MIQ_ROW_LAUNCH_E(sizeof(T), KERN, T, VEC_OK, GEO, STREAM, __VA_ARGS__)
 
 constexpr int kRowMaxPacks = 8192;
 

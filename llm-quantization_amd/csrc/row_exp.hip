@@ -129,14 +129,16 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     row_minmax(x, padded, lds, rmin, rmax);
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
     const typename BwdDivisorOf<T>::type dv(c.s);
+    const float hi_dead = rnd<T>(c.top + 0.0001f), lo_dead = rnd<T>(-c.top + 0.0001f);
     auto grad_q = [&](float gv, const Exp2Elem& el) {
         float gq = gv * c.s;
         if (el.sign == -1.f) gq = -gq;
         // the comparison constants are rounded to the tensor dtype, as the reference's `q_exp.ge(qmax+0.0001)` does
-        const bool dead = (el.lvl >= rnd<T>(c.top + 0.0001f)) || (el.lvl <= rnd<T>(-c.top + 0.0001f)) || el.is_zero || el.below;
-        if (dead) return 0.f;
-        // gradients are tolerance-checked sums: reciprocal multiplies instead of IEEE divisions
-        return (((kLn2 * el.lvl) * gq) * kInvLn2 * __frcp_rn(el.mag)) * el.sign;
+        // (bitwise | and a select: with || and an early return the compiler branches around the product for every element)
+        const bool dead = (el.lvl >= hi_dead) | (el.lvl <= lo_dead) | el.is_zero | el.below;
+        // gradients are tolerance-checked sums: the hardware reciprocal (1 ulp) instead of an IEEE division (__frcp_rn is one)
+        const float v = (((kLn2 * el.lvl) * gq) * kInvLn2 * __builtin_amdgcn_rcpf(el.mag)) * el.sign;
+        return dead ? 0.f : v;
     };
     const float inv_s = 1.0f / c.s, neg_inv_s2 = -1.0f / (c.s * c.s);
     // The per-element gradient w.r.t. x/s is needed again for dx: keep it instead of redoing the log2 / level
@@ -302,9 +304,10 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     const typename BwdDivisorOf<T>::type dv(c.s);
     const float alo = rnd<T>(kClipLo);
     auto d_u = [&](float gv, const Exp1Elem& el) {
-        const bool live = (el.lround >= c.e_lo) && (el.lround <= 0.f) && (fabsf(el.u) >= alo) && (fabsf(el.u) <= kClipHi);
-        if (!live) return 0.f;
-        return ((kLn2 * el.p) * ((gv * c.s) * el.sign)) * __frcp_rn(el.mag * kLn2) * sgnf(el.u);
+        // (bitwise & and a select: with && and an early return the compiler branches around the product for every element)
+        const bool live = (el.lround >= c.e_lo) & (el.lround <= 0.f) & (fabsf(el.u) >= alo) & (fabsf(el.u) <= kClipHi);
+        const float v = ((kLn2 * el.p) * ((gv * c.s) * el.sign)) * __builtin_amdgcn_rcpf(el.mag * kLn2) * sgnf(el.u);
+        return live ? v : 0.f;
     };
     const float inv_s = 1.0f / c.s, neg_inv_s2 = -1.0f / (c.s * c.s);
     constexpr bool kInPlace = sizeof(T) == 4;  // see k_exp2_bwd
@@ -394,10 +397,10 @@ static int launch_exp(int which, bool backward, const void* gout, const void* x,
     a.preact = (flags >> 1) & 1;
     if (which == 2) {
         if (!backward) MIQ_ROW_LAUNCH(k_exp2_fwd, T, vec_ok, geo, stream, a, geo, (T*)out_or_dx, (T*)a1);
-        else MIQ_ROW_LAUNCH(k_exp2_bwd, T, vec_ok, geo, stream, a, geo, (const T*)gout, (T*)out_or_dx, (T*)a1, (T*)a2);
+        else MIQ_ROW_LAUNCH_SIZED(k_exp2_bwd, T, vec_ok, geo, stream, a, geo, (const T*)gout, (T*)out_or_dx, (T*)a1, (T*)a2);
     } else {
         if (!backward) MIQ_ROW_LAUNCH(k_exp1_fwd, T, vec_ok, geo, stream, a, geo, (T*)out_or_dx, (T*)a1, (T*)a2);
-        else MIQ_ROW_LAUNCH(k_exp1_bwd, T, vec_ok, geo, stream, a, geo, (const T*)gout, (T*)out_or_dx, (T*)a1, (T*)a2);
+        else MIQ_ROW_LAUNCH_SIZED(k_exp1_bwd, T, vec_ok, geo, stream, a, geo, (const T*)gout, (T*)out_or_dx, (T*)a1, (T*)a2);
     }
     MIQ_CHECK_LAUNCH(name);
     return 0;

@@ -125,9 +125,10 @@ __device__ __forceinline__ void uniform_fwd_row(const UniArgs<T>& a, const RowGe
         if (level_div_ok(c.s)) quantize_row(std::true_type{}, LevelDivisor(c.s));
         else quantize_row(std::true_type{}, Divisor<T>(c.s));
     } else {
-        const Divisor<T> dv(c.s);
-        if (exact_int) quantize_row(std::true_type{}, dv);
-        else quantize_row(std::false_type{}, dv);
+        // the usual row: integer levels exact in fp16 and a finite, non-zero scale; anything else takes the general form
+        // (re-rounding every integer step is correct for every row, only slower)
+        if (exact_int && half_div_ok(c.s)) quantize_row(std::true_type{}, HalfDivisor(c.s));
+        else quantize_row(std::false_type{}, Divisor<T>(c.s));
     }
 }
 
@@ -240,9 +241,8 @@ __device__ __forceinline__ void uniform_bwd_row(const UniArgs<T>& a, const RowGe
         if (level_div_ok(c.s)) row_sums(std::true_type{}, LevelDivisor(c.s));
         else row_sums(std::true_type{}, Divisor<T>(c.s));
     } else {
-        const Divisor<T> dv(c.s);
-        if (exact_int) row_sums(std::true_type{}, dv);
-        else row_sums(std::false_type{}, dv);
+        if (exact_int && half_div_ok(c.s)) row_sums(std::true_type{}, HalfDivisor(c.s));
+        else row_sums(std::false_type{}, Divisor<T>(c.s));
     }
     team_sum<TEAM, 3>(acc, lds);
     if (WANT_DX && padded) {
