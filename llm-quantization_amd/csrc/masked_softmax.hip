@@ -57,6 +57,8 @@ __device__ __forceinline__ void masked_scores(const SmArgs& a, const RowTile<TX,
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
         float mv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) mv[e] = 0.f;  // no mask: w + 0 is w
         if (a.mask) {
             if (a.mask_half) {
                 const Pack<__half, VEC> m = ld_pack<__half, VEC>(reinterpret_cast<const __half*>(a.mask) + mrow * a.C + x.offset(k));
@@ -72,13 +74,16 @@ __device__ __forceinline__ void masked_scores(const SmArgs& a, const RowTile<TX,
                 }
             }
         }
+        // No test of the launch's options per element (the compiler keeps each as a scalar branch around one or two
+        // instructions, a hundred of them per row tile): a divisor of 1 multiplies exactly, an absent mask adds 0, and
+        // the rounding of an fp16 sum is a select.
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float t = to_f<TX>(x.v[k].e[e]);
-            if (a.inv_div != 1.0f) t = rnd<TX>(t * a.inv_div);
-            if (a.mask) {
-                t = t + mv[e];
-                if (a.sum_half) t = rnd<__half>(t);
+            float t = rnd<TX>(to_f<TX>(x.v[k].e[e]) * a.inv_div);
+            t = t + mv[e];
+            if constexpr (sizeof(TX) == 2) {
+                const float th = rnd<__half>(t);
+                t = a.sum_half ? th : t;
             }
             v[k][e] = t;
         }
