@@ -70,22 +70,28 @@ __device__ __forceinline__ LetCtx let_ctx(const LetArgs& a, long long row, float
 template <int TEAM, int NV>
 struct ColVec {
     float4 v[NV];
-    __device__ __forceinline__ void load(const float* p, int npack, int lane) {
+    // packs beyond the row re-read the last one (their elements are never used); a null vector reads as `fill`
+    __device__ __forceinline__ void load(const float* p, int npack, int lane, float fill) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = make_float4(fill, fill, fill, fill);
+        if (!p) return;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int j = k * TEAM + lane;
-            v[k] = (p && j < npack) ? *reinterpret_cast<const float4*>(p + (long long)j * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+            v[k] = *reinterpret_cast<const float4*>(p + (long long)(j < npack ? j : npack - 1) * 4);
         }
     }
     __device__ __forceinline__ float at(int k, int e) const { return reinterpret_cast<const float*>(&v[k])[e]; }
-    __device__ __forceinline__ float& at(int k, int e) { return reinterpret_cast<float*>(&v[k])[e]; }
 };
 
-// t = (w * cs) [/ or *] r, in this order, every step rounded to fp32 like the PyTorch ops it replaces
-__device__ __forceinline__ float let_apply(float w, float cs, bool has_cs, float r, bool has_r, bool rdiv) {
-    float t = has_cs ? w * cs : w;
-    if (has_r) t = rdiv ? t / r : t * r;
-    return t;
+// t = (w * cs) [/ or *] r, in this order, every step rounded to fp32 like the PyTorch ops it replaces.  Which of the
+// factors exist is a property of the launch: an absent factor is passed as 1 (x * 1 is x, bit for bit), and division
+// against multiplication is a template parameter, so that the element loops carry no test of the launch's options (left
+// inside, each test stays a scalar branch around one or two instructions, three per element).
+template <bool RDIV>
+__device__ __forceinline__ float let_apply(float w, float cs, float r) {
+    const float t = w * cs;
+    return RDIV ? t / r : t * r;
 }
 // The same for the backward kernels, with the corrected reciprocal product x * rr, rr = 1 / r, in place of the
 // division (UncheckedDivisor: the IEEE quotient for every finite operand pair away from the ends of the exponent
@@ -94,23 +100,28 @@ __device__ __forceinline__ float quot(float x, float d, float rd) {
     const float q0 = x * rd;
     return __builtin_fmaf(__builtin_fmaf(-q0, d, x), rd, q0);
 }
-__device__ __forceinline__ float let_apply_bwd(float w, float cs, bool has_cs, float r, float rr, bool has_r, bool rdiv) {
-    float t = has_cs ? w * cs : w;
-    if (has_r) t = rdiv ? quot(t, r, rr) : t * r;
-    return t;
+template <bool RDIV>
+__device__ __forceinline__ float let_apply_bwd(float w, float cs, float r, float rr) {
+    const float t = w * cs;
+    return RDIV ? quot(t, r, rr) : t * r;
 }
 
-template <typename TO, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
+template <typename TO, int TEAM, int NV, bool RDIV>
+// (the 6-pack tile sits at 128 to 130 registers: held to 128, two of its 512-thread blocks share a CU)
+__global__ void __launch_bounds__(block_of<TEAM>(), NV == 6 ? 4 : 1)
 k_let_fwd(LetArgs a, TO* __restrict__ out, float* __restrict__ scale_out, float* __restrict__ rzp_out,
           float* __restrict__ wshift_out) {
     __shared__ float lds[48];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
     const int npack = a.I / 4;
-    const bool has_cs = a.cs != nullptr, has_r = a.rs != nullptr, rdiv = a.rs_div != 0;
-    (void)npack;
-    // one row per team per iteration; the column vectors (a few KB, L2-resident) are read at use
+    const bool has_r = a.rs != nullptr;
+    // The column vectors (a few KB, L2-resident) do not depend on the row: requested once, before the first row's data,
+    // with clamped indices instead of guards (a guarded load is issued behind its own branch, and read at its use inside
+    // the element loop each one exposed an L2 round trip).  Absent vectors are 1 / 0: x * 1 is x, x * 0 adds nothing.
+    ColVec<TEAM, NV> cvec, svec;
+    cvec.load(a.cs, npack, lane, 1.f);
+    svec.load(a.shift, npack, lane, 0.f);
     for (long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM; row < a.O; row += (long long)gridDim.x * RPB) {
         RowTile<float, 4, TEAM, NV> x;
         x.load(a.w + row * a.I, a.I, lane);
@@ -119,18 +130,11 @@ k_let_fwd(LetArgs a, TO* __restrict__ out, float* __restrict__ scale_out, float*
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
-            if (a.shift) {
-                const float4 s4 = *reinterpret_cast<const float4*>(a.shift + x.offset(k));
-                d[0] += x.v[k].e[0] * s4.x;
-                d[0] += x.v[k].e[1] * s4.y;
-                d[0] += x.v[k].e[2] * s4.z;
-                d[0] += x.v[k].e[3] * s4.w;
-            }
-            float4 c4 = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (has_cs) c4 = *reinterpret_cast<const float4*>(a.cs + x.offset(k));
-            const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x.v[k].e[e] = let_apply(x.v[k].e[e], cv[e], has_cs, r, has_r, rdiv);
+            for (int e = 0; e < 4; ++e) {
+                d[0] += x.v[k].e[e] * svec.at(k, e);
+                x.v[k].e[e] = let_apply<RDIV>(x.v[k].e[e], cvec.at(k, e), r);
+            }
         }
         if (a.shift) {
             team_sum<TEAM, 1>(d, lds);
@@ -181,7 +185,7 @@ struct RowCtx {
     float s, rzp, rmax, rmin, share_max, share_min, inv_s, inv_r;  // inv_*: 1 / s and 1 / rs[row]
 };
 
-template <typename TG, int TEAM, int NV>
+template <typename TG, int TEAM, int NV, bool RDIV>
 __global__ void __launch_bounds__(block_of<TEAM>(), 4)
 k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up, float* __restrict__ d_low,
                float* __restrict__ d_rs, RowCtx* __restrict__ rowctx) {
@@ -190,25 +194,22 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
     const int lane = threadIdx.x % TEAM;
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
     if (row >= a.O) return;
-    const int npack = a.I / 4;
-    const bool has_cs = a.cs != nullptr, has_r = a.rs != nullptr, rdiv = a.rs_div != 0;
+    const bool has_r = a.rs != nullptr;
     RowTile<float, 4, TEAM, NV> w;
     RowTile<TG, 4, TEAM, NV> g;
+    ColVec<TEAM, NV> cvec;
     w.load(a.w + row * a.I, a.I, lane);
     g.load(gout + row * a.I, a.I, lane);
+    cvec.load(a.cs, a.I / 4, lane, 1.f);  // requested with the row, not at its use
     const float r = has_r ? a.rs[row] : 1.f;
     const float rr = 1.0f / r;
-    // w.v <- t (the column factors are read once per element: the row kernel touches each once)
+    // w.v <- t
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (!w.has(k)) continue;
-        float4 c4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (has_cs) c4 = *reinterpret_cast<const float4*>(a.cs + w.offset(k));
-        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w.v[k].e[e] = let_apply_bwd(w.v[k].e[e], cv[e], has_cs, r, rr, has_r, rdiv);
+        for (int e = 0; e < 4; ++e) w.v[k].e[e] = let_apply_bwd<RDIV>(w.v[k].e[e], cvec.at(k, e), r, rr);
     }
-    (void)npack;
     float rmin, rmax;
     row_minmax(w, false, lds, rmin, rmax);
     const LetCtx c = let_ctx(a, row, rmin, rmax);
@@ -254,7 +255,7 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
         // sum_i dt*t with dt = m*g + shares at the extremes (t == rmax / rmin there): division by r for the
         // quotient rule, identity for the product rule (dt * t1 with t1 = t / r up to one rounding)
         const float sum_dt_t = acc[3] + tot_max * rmax + tot_min * rmin;
-        d_rs[row] = rdiv ? -sum_dt_t / r : sum_dt_t / r;
+        d_rs[row] = RDIV ? -sum_dt_t / r : sum_dt_t / r;
     }
     if (rowctx) {
         RowCtx o;
@@ -267,7 +268,7 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
     }
 }
 
-template <typename TG>
+template <typename TG, bool RDIV>
 __global__ void __launch_bounds__(256)
 k_let_bwd_cols(LetArgs a, const TG* __restrict__ gout, const float* __restrict__ g_wshift, const RowCtx* __restrict__ rowctx,
                int rows_per_chunk, float* __restrict__ part_cs, float* __restrict__ part_sh) {
@@ -275,7 +276,7 @@ k_let_bwd_cols(LetArgs a, const TG* __restrict__ gout, const float* __restrict__
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long col0 = ((long long)blockIdx.x * 64 + lane) * 4;
     const bool valid = col0 < a.I;
-    const bool has_cs = a.cs != nullptr, has_r = a.rs != nullptr, rdiv = a.rs_div != 0;
+    const bool has_cs = a.cs != nullptr, has_r = a.rs != nullptr;
     const bool want_cs = part_cs != nullptr, want_sh = part_sh != nullptr;
     const float qmax = exp2f((float)a.n_bits) - 1.0f;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
@@ -295,12 +296,12 @@ k_let_bwd_cols(LetArgs a, const TG* __restrict__ gout, const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float wv_ = w.e[e];
-                const float t = let_apply_bwd(wv_, cv[e], has_cs, r, c.inv_r, has_r, rdiv);
+                const float t = let_apply_bwd<RDIV>(wv_, cv[e], r, c.inv_r);
                 const float xi = rint_ste(quot(t, c.s, c.inv_s)) + c.rzp;
                 float dt = ((xi >= 0.f) && (xi <= qmax)) ? to_f<TG>(g.e[e]) : 0.f;
                 if (t == c.rmax) dt += c.share_max;
                 if (t == c.rmin) dt += c.share_min;
-                const float d_t1 = has_r ? (rdiv ? quot(dt, r, c.inv_r) : dt * r) : dt;
+                const float d_t1 = RDIV ? quot(dt, r, c.inv_r) : dt * r;  // r is 1 without a row factor
                 acs[e] += d_t1 * wv_;
                 ash[e] += wv_ * gs;
             }
@@ -356,12 +357,17 @@ k_colsum(const float* __restrict__ part, int nrows, int C, float* __restrict__ o
     if (w == 0 && c < C) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
+// 6-pack tiles for the 5120- and 11008-wide rows of Llama-2-13B / -7B: the 8-pack tile they would otherwise take holds
+// 150 to 170 registers in the forward kernel (row, column factors and shifts in registers), one block per CU; with 6
+// packs it is 128 and two blocks overlap (4096 x 11008 forward: 111 -> 77 us).
 #define LET_DISPATCH(NPACK, L)                   \
     do {                                         \
         if ((NPACK) <= 64) { L(16, 4); }         \
         else if ((NPACK) <= 256) { L(64, 4); }   \
         else if ((NPACK) <= 1024) { L(256, 4); } \
+        else if ((NPACK) <= 1536) { L(256, 6); } \
         else if ((NPACK) <= 2048) { L(256, 8); } \
+        else if ((NPACK) <= 3072) { L(512, 6); } \
         else { L(512, 8); }                      \
     } while (0)
 
@@ -395,9 +401,14 @@ static void let_fwd_launch(const LetArgs& a, void* out, float* scale_out, float*
     const int npack = a.I / 4;
     const int rpb = let_rpb(npack);
     const unsigned grid = (unsigned)((a.O + rpb - 1) / rpb);
-#define L(TEAM, NV)                                                                                                   \
-    hipLaunchKernelGGL((k_let_fwd<TO, TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a, (TO*)out, scale_out, \
-                       rzp_out, wshift_out)
+    const bool rdiv = a.rs != nullptr && a.rs_div != 0;
+#define L(TEAM, NV)                                                                                                    \
+    if (rdiv)                                                                                                          \
+        hipLaunchKernelGGL((k_let_fwd<TO, TEAM, NV, true>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a, (TO*)out, \
+                           scale_out, rzp_out, wshift_out);                                                            \
+    else                                                                                                               \
+        hipLaunchKernelGGL((k_let_fwd<TO, TEAM, NV, false>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a, (TO*)out, \
+                           scale_out, rzp_out, wshift_out)
     LET_DISPATCH(npack, L);
 #undef L
 }
@@ -410,9 +421,14 @@ static void let_bwd_launch(const LetArgs& a, const void* gout, const float* g_ws
     const unsigned grid = (unsigned)((a.O + rpb - 1) / rpb);
     const bool cols = d_cs || d_shift;
     RowCtx* rowctx = cols ? reinterpret_cast<RowCtx*>(ws) : nullptr;
+    const bool rdiv = a.rs != nullptr && a.rs_div != 0;
 #define L(TEAM, NV)                                                                                                    \
-    hipLaunchKernelGGL((k_let_bwd_rows<TG, TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a, (const TG*)gout, \
-                       d_up, d_low, d_rs, rowctx)
+    if (rdiv)                                                                                                          \
+        hipLaunchKernelGGL((k_let_bwd_rows<TG, TEAM, NV, true>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a,     \
+                           (const TG*)gout, d_up, d_low, d_rs, rowctx);                                                \
+    else                                                                                                               \
+        hipLaunchKernelGGL((k_let_bwd_rows<TG, TEAM, NV, false>), dim3(grid), dim3(block_of<TEAM>()), 0, stream, a,    \
+                           (const TG*)gout, d_up, d_low, d_rs, rowctx)
     LET_DISPATCH(npack, L);
 #undef L
     if (!cols) return;
@@ -421,8 +437,12 @@ static void let_bwd_launch(const LetArgs& a, const void* gout, const float* g_ws
     float* part_cs = d_cs ? ws + 8 * a.O : nullptr;
     float* part_sh = d_shift ? ws + 8 * a.O + (d_cs ? (long long)nchunk * a.I : 0) : nullptr;
     const unsigned tiles = (unsigned)((npack + 63) / 64);
-    hipLaunchKernelGGL((k_let_bwd_cols<TG>), dim3(tiles, nchunk), dim3(256), 0, stream, a, (const TG*)gout, g_wshift, rowctx, rpc,
-                       part_cs, part_sh);
+    if (rdiv)
+        hipLaunchKernelGGL((k_let_bwd_cols<TG, true>), dim3(tiles, nchunk), dim3(256), 0, stream, a, (const TG*)gout, g_wshift, rowctx,
+                           rpc, part_cs, part_sh);
+    else
+        hipLaunchKernelGGL((k_let_bwd_cols<TG, false>), dim3(tiles, nchunk), dim3(256), 0, stream, a, (const TG*)gout, g_wshift, rowctx,
+                           rpc, part_cs, part_sh);
     const unsigned fg = (unsigned)((a.I + 63) / 64);
     if (d_cs) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, stream, part_cs, nchunk, a.I, d_cs);
     if (d_shift) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, stream, part_sh, nchunk, a.I, d_shift);
