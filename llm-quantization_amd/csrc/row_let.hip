@@ -334,10 +334,14 @@ k_let_bwd_cols(LetArgs a, const TG* __restrict__ gout, const float* __restrict__
     if (want_sh) *reinterpret_cast<float4*>(part_sh + (long long)blockIdx.y * a.I + col0) = fold(1);
 }
 
-// out[c] = sum over the nrows partial rows; block = 64 columns x 4 waves (wave w takes rows w, w+4, ...)
+// out[c] = sum over the nrows partial rows; block = 64 columns x 4 waves (wave w takes rows w, w+4, ...).  blockIdx.y
+// picks one of up to two (partials, output) pairs, so the column-factor and the shift gradient fold in one launch.
 __global__ void __launch_bounds__(256)
-k_colsum(const float* __restrict__ part, int nrows, int C, float* __restrict__ out) {
+k_colsum(const float* __restrict__ part0, float* __restrict__ out0, const float* __restrict__ part1, float* __restrict__ out1,
+         int nrows, int C) {
     __shared__ float sm[4][64];
+    const float* __restrict__ part = blockIdx.y ? part1 : part0;
+    float* __restrict__ out = blockIdx.y ? out1 : out0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -444,8 +448,9 @@ static void let_bwd_launch(const LetArgs& a, const void* gout, const float* g_ws
         hipLaunchKernelGGL((k_let_bwd_cols<TG, false>), dim3(tiles, nchunk), dim3(256), 0, stream, a, (const TG*)gout, g_wshift, rowctx,
                            rpc, part_cs, part_sh);
     const unsigned fg = (unsigned)((a.I + 63) / 64);
-    if (d_cs) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, stream, part_cs, nchunk, a.I, d_cs);
-    if (d_shift) hipLaunchKernelGGL(k_colsum, dim3(fg), dim3(256), 0, stream, part_sh, nchunk, a.I, d_shift);
+    if (d_cs && d_shift) hipLaunchKernelGGL(k_colsum, dim3(fg, 2), dim3(256), 0, stream, part_cs, d_cs, part_sh, d_shift, nchunk, a.I);
+    else if (d_cs) hipLaunchKernelGGL(k_colsum, dim3(fg, 1), dim3(256), 0, stream, part_cs, d_cs, nullptr, nullptr, nchunk, a.I);
+    else hipLaunchKernelGGL(k_colsum, dim3(fg, 1), dim3(256), 0, stream, part_sh, d_shift, nullptr, nullptr, nchunk, a.I);
 }
 
 }  // namespace miq
