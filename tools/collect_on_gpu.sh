@@ -37,6 +37,8 @@ python3 tools/row_pmc_summary.py "$D"/sq_rows/*/*counter_collection.csv "$D/sq_r
 python3 tools/row_pmc_summary.py "$D"/sq_bench/*/*counter_collection.csv "$D/sq_bench.json" > /dev/null
 echo "[collect] row-sharded workload, one GPU"; timeout -k 10 300 python3 -u bench.py --workload c4 --steps 10 --warmup 3 > "$D/bench_c4.json.log" 2> "$D/bench_c4.err"
 echo "[collect] norm + quantizer, separate against fused"; timeout -k 10 120 python3 -u tools/dev/norm_quant_time.py > "$D/norm_quant_time.txt" 2>&1
+echo "[collect] LET kernels, attention-score pass"; timeout -k 10 200 python3 -u tools/bench_let.py > "$D/bench_let.txt" 2>&1
+timeout -k 10 120 python3 -u tools/dev/softmax_time.py > "$D/softmax_time.txt" 2>&1
 echo "[collect] micro-benchmarks"
 for b in actbench readbw statbench; do
     if [ -x tools/ubench/$b ]; then timeout -k 10 120 tools/ubench/$b > "$D/ubench_$b.txt" 2>&1; fi

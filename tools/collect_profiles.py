@@ -28,7 +28,8 @@ def main():
     for name, dst in (("sq_rows.json", "sq_rows.json"), ("sq_bench.json", "sq_bench.json"), ("bench_c4.json.log", "bench_c4.json.log"),
                       ("norm_quant_time.txt", "norm_quant_time.txt"), ("ubench_actbench.txt", "ubench_actbench.txt"),
                       ("ubench_readbw.txt", "ubench_readbw.txt"), ("ubench_statbench.txt", "ubench_statbench.txt"),
-                      ("ab_block.json", "ab_block.json")):
+                      ("ab_block.json", "ab_block.json"), ("bench_let.txt", "bench_let.txt"),
+                      ("softmax_time.txt", "softmax_time.txt")):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(prof, f"{tag}_{dst}"))
     b7 = glob.glob(os.path.join(src, "block7b", "*", "*kernel_stats.csv"))
