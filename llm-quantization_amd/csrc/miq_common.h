@@ -169,7 +169,9 @@ struct HalfDivisor {
     __device__ __forceinline__ explicit HalfDivisor(float s_) : s(s_), rs(1.0f / s_) {}
     __device__ __forceinline__ float div(float x) const {
         const float q0 = x * rs;
-        return __half2float(__float2half(__builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0)));
+        const float q = __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
+        // an infinite x (or product) has no finite residual: the quotient is the product itself; NaN stays NaN
+        return __half2float(__float2half(fabsf(q0) < __builtin_inff() ? q : q0));
     }
 };
 __device__ __forceinline__ bool half_div_ok(float s) {
@@ -195,7 +197,7 @@ template <> struct Divisor<__half> {
         if (fast) {
             const float q0 = x * rs;
             const float e = __builtin_fmaf(-q0, s, x);
-            q = __builtin_fmaf(e, rs, q0);
+            q = fabsf(q0) < __builtin_inff() ? __builtin_fmaf(e, rs, q0) : q0;
         } else {
             q = x / s;
         }
@@ -237,7 +239,7 @@ template <> __device__ __forceinline__ float col_div<float>(float x, float s, fl
 template <> __device__ __forceinline__ float col_div<__half>(float x, float s, float rs) {
     const float q0 = x * rs;
     const float e = __builtin_fmaf(-q0, s, x);   // exact residual: see Divisor<__half>
-    return __half2float(__float2half(__builtin_fmaf(e, rs, q0)));
+    return __half2float(__float2half(fabsf(q0) < __builtin_inff() ? __builtin_fmaf(e, rs, q0) : q0));
 }
 template <typename T>
 __device__ __forceinline__ float col_level(float x, float s, float rs, float z, bool exact_int) {

@@ -221,3 +221,33 @@ def test_bad_arguments():
         F.act_fresh_quant_fwd([x] * 9, 4, layout)
     with pytest.raises(L.MiqError):
         F.act_fresh_quant_fwd([x, torch.zeros((4, 16), device=DEV, dtype=torch.float16)], 4, layout)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("counts", [[128] * 4, None])
+def test_infinite_nan_and_huge_activations_match_the_oracle(dt, counts):
+    """Channels that hold an infinity, a NaN, the largest finite value or only zeros: the clamped scale keeps the
+    corrected quotient in use, which must still give the reference's outputs, codes and statistics."""
+    dtype = DT[dt]
+    R, C = 96, 512
+    layout = F.ClusterLayout.get(counts, C, DEV)
+    kw = dict(method="per_cluster" if counts else "per_tensor", metric="minmax", cluster_dim=1 if counts else None,
+              cluster_counts=counts)
+    for special in (float("inf"), -float("inf"), float("nan"), torch.finfo(dtype).max, 0.0):
+        x = synth.activation((R, C), 77, dtype)
+        x[:, 130:140] = 0.0
+        if special == 0.0:
+            x[:, 256:384] = 0.0      # one whole cluster of zeros
+        else:
+            x[5, 3] = special        # first cluster
+            x[70, 300] = special     # third cluster
+        xd = x.to(DEV)
+        outs, codes, vecs = F.act_fresh_quant_fwd([xd], 4, layout, want_codes=True)
+        st = F.stats_of(vecs[0])
+        ref, ref_codes = O.act_forward(x, (ost := O.ActState()), 4, "calibration", **kw)
+        vec = lambda t: t.reshape(-1).expand(C) if t.numel() == 1 else t.reshape(-1)
+        assert same(st["scale"].cpu(), vec(ost.scale)) and same(st["rzp"].cpu(), vec(ost.rzp)), special
+        assert same(outs[0].cpu(), ref), special
+        assert torch.equal(codes[0].cpu().to(torch.int32), torch.nan_to_num(ref_codes, nan=0.0).to(torch.int32)), special
+        o_out, o_codes, o_st = F.act_calib_quant_fwd(xd, 4, "minmax", layout, want_codes=True)
+        assert same(o_out.cpu(), ref) and torch.equal(o_codes, codes[0]), special

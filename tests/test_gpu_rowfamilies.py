@@ -315,3 +315,32 @@ def test_row_sharded_weight_quantization_equals_full():
         o, s, z, _ = F.rowquant_uniform_fwd(x[a:b].contiguous(), 4, False, up[a:b].contiguous(), low[a:b].contiguous())
         parts.append(o)
     assert torch.equal(torch.cat(parts), full)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_exponent_grids_on_degenerate_rows(dt):
+    """Zero, constant, infinite, NaN, subnormal and huge rows through both exponent quantizers: the scale is clamped, so
+    every row takes the corrected product; the forward must still give the reference's bits on each of them."""
+    g = torch.Generator().manual_seed(12)
+    width = 1024
+    big = 6.0e4 if dt == torch.float16 else 3.0e38
+    tiny = 6.0e-8 if dt == torch.float16 else 1.0e-42
+    x = torch.randn(8, width, generator=g) * 0.02
+    x[0] = 0.0
+    x[1] = 0.5
+    x[2, 5] = float("inf")
+    x[3, 7] = float("nan")
+    x[4] = torch.randn(width, generator=g).sign() * tiny
+    x[5] = torch.randn(width, generator=g).sign() * big
+    x[6, ::2] = 0.0
+    x = x.to(dt)
+    for bits in (2, 3, 4):
+        r = O.exp2_row(x, bits)
+        out, scale = F.rowquant_exp2_fwd(x.to(DEV), bits)
+        assert same(scale.cpu(), r.scale)
+        check_exp_forward(x, r.scale, out, r.out, 2)
+        for symmetric in (True, False):
+            r1 = O.exp1_row(x, bits, symmetric)
+            out1, scale1, mid1 = F.rowquant_exp1_fwd(x.to(DEV), bits, symmetric)
+            assert same(scale1.cpu(), r1.scale)
+            check_exp_forward(x, r1.scale, out1, r1.out, 1)

@@ -202,3 +202,38 @@ def test_backward_at_llama_row_widths(I, dt):
         ok = torch.isfinite(b)
         z = torch.zeros_like(b)
         assert rel_err(torch.where(ok, a.cpu(), z).float(), torch.where(ok, b, z).float()) <= 4 * tol, name
+
+
+def _degenerate_rows(dtype, width):
+    """Rows that leave the usual range of a weight row: zeros, constants, an infinity, a NaN, subnormal and huge values."""
+    g = torch.Generator().manual_seed(11)
+    big = 6.0e4 if dtype == torch.float16 else 3.0e38
+    tiny = 6.0e-8 if dtype == torch.float16 else 1.0e-42
+    x = torch.randn(10, width, generator=g) * 0.02
+    x[0] = 0.0
+    x[1] = 0.5
+    x[2] = -3.0
+    x[3, 5] = float("inf")
+    x[4, 7] = float("nan")
+    x[5] = torch.randn(width, generator=g).sign() * tiny
+    x[6] = torch.randn(width, generator=g).sign() * big
+    x[7, ::2] = 0.0          # half zeros
+    x[8, 3] = -float("inf")
+    x = x.to(dtype)          # row 9 stays an ordinary row
+    return x
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("sym", [False, True])
+@pytest.mark.parametrize("width", [512, 4096])
+def test_degenerate_rows_match_the_oracle(dt, sym, width):
+    """Rows whose scale is zero, infinite or NaN (an asymmetric scale is not clamped) take the kernels' general quotient,
+    chosen once per row; ordinary rows beside them take the corrected product.  Both must give the reference's bits."""
+    x = _degenerate_rows(DT[dt], width)
+    for bits in (4, 8):
+        r = O.uniform_row(x, bits, sym)
+        out, scale, rzp, codes = F.rowquant_uniform_fwd(x.to(DEV), bits, sym, want_codes=True)
+        check_exact(out, scale, rzp, None, r.out, r.scale, r.rzp, None)
+        outs, scales, rzps = F.rowquant_uniform_fwd_batch([x.to(DEV), x.flip(0).contiguous().to(DEV)], bits, sym)
+        assert same(outs[0].cpu(), r.out) and same(outs[1].cpu(), r.out.flip(0))
+        assert same(scales[0].cpu(), r.scale) and same(rzps[0].cpu(), r.rzp)
