@@ -27,8 +27,11 @@ CASES = [
     (768, 768, True, "mul", True, True, False, 4),
     (3072, 768, True, None, True, True, False, 2),
     (1024, 4096, True, "div", True, True, False, 4),     # TEAM 256 x 4 packs, 512 blocks x 2 rows
-    (600, 5120, True, "mul", True, True, False, 4),      # 256 x 8
-    (300, 11008, True, None, True, True, False, 4),      # 512 x 8
+    (600, 5120, True, "mul", True, True, False, 4),      # 256 x 6
+    (300, 11008, True, None, True, True, False, 4),      # 512 x 6
+    (300, 11008, True, "div", True, True, False, 4),
+    (200, 8192, True, "div", True, True, False, 4),      # 256 x 8
+    (100, 13824, True, "mul", True, True, False, 4),     # 512 x 8
     (4096, 4096, False, None, False, True, False, 4),    # plain quantizer through the fused kernels
 ]
 
@@ -78,7 +81,7 @@ def test_let_fused_matches_chain(O_, I, cs, rs, shift, lwc, sym, bits):
     assert same(rzp.cpu(), res.rzp.detach()), "rounded zero point"
     assert same(out.cpu(), res.out.detach()), "quantized weight"
     if shift:
-        assert rel_err(wshift.cpu(), wshift_ref.detach()) <= 1e-6
+        assert rel_err(wshift.cpu(), wshift_ref.detach()) <= (1e-6 if I <= 4096 else 3e-6)  # fp32 dot products, other order
     d_cs, d_rs, d_shift, d_su, d_sl = F.let_rowquant_bwd(dev(d["g"]), dev(d["gb"]) if shift else None, dev(d["w"]), dev(d["cs"]),
                                                          dev(d["rs"]), rs == "div", dev(d["shift"]), dev(su), dev(sl), bits, sym,
                                                          preactivated=True)
@@ -149,3 +152,37 @@ def test_truncate_inplace_matches_truncate_number(dt):
     for a, b in zip(vecs, want):
         assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
         assert torch.equal(torch.signbit(a), torch.signbit(b))
+
+
+@pytest.mark.parametrize("rs", [None, "div", "mul"])
+def test_let_fused_forward_on_degenerate_rows(rs):
+    """Rows of zeros, constants, an infinity, a NaN, subnormal and huge values: a row whose scale is zero, infinite or NaN
+    takes the plain division (chosen per row), its neighbours the rounded-level product; all must give the chain's bits."""
+    g = synth.gen(901)
+    O_, I = 12, 1024
+    w = synth.weight(O_, I, 902)
+    w[0] = 0.0
+    w[1] = 0.25
+    w[2, 9] = float("inf")
+    w[3, 11] = float("nan")
+    w[4] = torch.randn(I, generator=g).sign() * 1e-42
+    w[5] = torch.randn(I, generator=g).sign() * 3e38
+    w[6, ::2] = 0.0
+    w[7, 5] = -float("inf")
+    cs = torch.rand(I, generator=g) * 2 + 0.25
+    r = (torch.rand(O_, generator=g) * 2 + 0.25) if rs else None
+    shift = torch.randn(I, generator=g) * 0.1
+    for sym in (False, True):
+        t = w * cs.view(1, -1)
+        if rs == "div":
+            t = t / r.view(-1, 1)
+        elif rs == "mul":
+            t = t * r.view(-1, 1)
+        res = O.uniform_row(t, 4, sym)
+        dev = lambda x: None if x is None else x.to(DEV)
+        out, wshift, scale, rzp = F.let_rowquant_fwd(dev(w), dev(cs), dev(r), rs == "div", dev(shift), None, None, 4, sym)
+        assert same(scale.cpu(), res.scale), "scale"
+        assert same(rzp.cpu(), res.rzp), "rounded zero point"
+        assert same(out.cpu(), res.out), "quantized weight"
+        out16 = F.let_rowquant_fwd(dev(w), dev(cs), dev(r), rs == "div", dev(shift), None, None, 4, sym, out_dtype=torch.float16)[0]
+        assert same(out16.cpu(), res.out.half()), "fp16 store"
