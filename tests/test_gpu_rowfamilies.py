@@ -344,3 +344,32 @@ def test_exponent_grids_on_degenerate_rows(dt):
             out1, scale1, mid1 = F.rowquant_exp1_fwd(x.to(DEV), bits, symmetric)
             assert same(scale1.cpu(), r1.scale)
             check_exp_forward(x, r1.scale, out1, r1.out, 1)
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_mixed_bit_grids_on_degenerate_rows(hard):
+    """The learnable and the fixed mixed-bit quantizer on rows of zeros, constants, infinities, NaN, subnormal and huge
+    values, with bit-widths 2 to 8 spread over the rows: forward bits of the reference on every row."""
+    g = torch.Generator().manual_seed(13)
+    width = 1024
+    x = torch.randn(16, width, generator=g) * 0.02
+    x[0] = 0.0
+    x[1] = 0.5
+    x[2, 5] = float("inf")
+    x[3, 7] = float("nan")
+    x[4] = torch.randn(width, generator=g).sign() * 1e-42
+    x[5] = torch.randn(width, generator=g).sign() * 3e38
+    x[6, ::2] = 0.0
+    x[7, 3] = -float("inf")
+    nb = torch.linspace(2.0, 8.0, 16).view(-1, 1) + (0.0 if hard else 0.37)
+    nb = nb.clamp(2, 8)
+    for symmetric in (False, True):
+        r = O.mix_row(x, nb.clone(), symmetric, None, None, None, hard, 0.0)
+        out = F.rowquant_mix_fwd(x.to(DEV), nb.reshape(-1).to(DEV), symmetric, None, None, 0, hard, 0.0)
+        assert same(out.cpu(), r.out), ("learnable", symmetric)
+    bits = (torch.arange(16) % 7 + 2).float()
+    for symmetric in (False, True):
+        r2 = O.uniform_row(x, bits.unsqueeze(-1), symmetric, None, None, None, clamp_asym_scale=True)
+        out2, scale2, rzp2, _ = F.rowquant_uniform_fwd(x.to(DEV), 0, symmetric, None, None, 0, bits.to(DEV), True)
+        assert same(scale2.cpu(), r2.scale) and same(rzp2.cpu(), r2.rzp), ("fixed", symmetric)
+        assert same(out2.cpu(), r2.out), ("fixed", symmetric)
