@@ -39,6 +39,7 @@ struct SmArgs {
     int C;
     long long rows_per_batch;  // heads * q_len score rows share one batch entry of the mask
     int q_len;
+    int head_block;      // heads a block walks per query row (set by the launcher)
 };
 
 struct OpMaxNan {
@@ -49,45 +50,80 @@ __device__ __forceinline__ long long mask_row(const SmArgs& a, long long row) {
     return (row / a.rows_per_batch) * a.q_len + row % a.q_len;
 }
 
-// v = x / div + mask of one row, with the roundings of the PyTorch chain; the caller applies the floor
-template <typename TX, int VEC, int TEAM, int NV>
-__device__ __forceinline__ void masked_scores(const SmArgs& a, const RowTile<TX, VEC, TEAM, NV>& x, long long row, float (&v)[NV][VEC]) {
-    const long long mrow = a.mask ? mask_row(a, row) : 0;
+// The mask values of one score row in registers, in the row tile's geometry.  Every head of a batch entry adds the same
+// [q_len, C] mask, so a block that walks several heads of one query row loads them once (a 2048 x 2048 fp32 mask re-read
+// by each of 32 heads is twice the traffic of the fp16 scores themselves, and it shows: 31 us of a 121 us forward).
+template <int VEC, int TEAM, int NV>
+struct MaskTile {
+    float m[NV][VEC];
+    template <typename TX>
+    __device__ __forceinline__ void load(const SmArgs& a, long long row, const RowTile<TX, VEC, TEAM, NV>& geo) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
-        float mv[VEC];
+        for (int k = 0; k < NV; ++k)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) mv[e] = 0.f;  // no mask: w + 0 is w
-        if (a.mask) {
+            for (int e = 0; e < VEC; ++e) m[k][e] = 0.f;  // no mask: w + 0 is w
+        if (!a.mask) return;
+        const long long mrow = mask_row(a, row);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!geo.has(k)) continue;
             if (a.mask_half) {
-                const Pack<__half, VEC> m = ld_pack<__half, VEC>(reinterpret_cast<const __half*>(a.mask) + mrow * a.C + x.offset(k));
+                const Pack<__half, VEC> p = ld_pack<__half, VEC>(reinterpret_cast<const __half*>(a.mask) + mrow * a.C + geo.offset(k));
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) mv[e] = __half2float(m.e[e]);
+                for (int e = 0; e < VEC; ++e) m[k][e] = __half2float(p.e[e]);
             } else {
-                const float* mp = reinterpret_cast<const float*>(a.mask) + mrow * a.C + x.offset(k);
+                const float* mp = reinterpret_cast<const float*>(a.mask) + mrow * a.C + geo.offset(k);
 #pragma unroll
                 for (int q = 0; q < VEC / 4; ++q) {  // 16-byte loads: VEC is 4 or 8
-                    const Pack<float, 4> m = ld_pack<float, 4>(mp + 4 * q);
+                    const Pack<float, 4> p = ld_pack<float, 4>(mp + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) mv[4 * q + e] = m.e[e];
+                    for (int e = 0; e < 4; ++e) m[k][4 * q + e] = p.e[e];
                 }
             }
         }
-        // No test of the launch's options per element (the compiler keeps each as a scalar branch around one or two
-        // instructions, a hundred of them per row tile): a divisor of 1 multiplies exactly, an absent mask adds 0, and
-        // the rounding of an fp16 sum is a select.
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float t = rnd<TX>(to_f<TX>(x.v[k].e[e]) * a.inv_div);
-            t = t + mv[e];
-            if constexpr (sizeof(TX) == 2) {
-                const float th = rnd<__half>(t);
-                t = a.sum_half ? th : t;
-            }
-            v[k][e] = t;
-        }
     }
+};
+
+// v = x / div + mask of one row, with the roundings of the PyTorch chain; the caller applies the floor.
+// No test of the launch's options per element (the compiler keeps each as a scalar branch around one or two
+// instructions, a hundred of them per row tile): a divisor of 1 multiplies exactly, an absent mask adds 0, and the
+// rounding of an fp16 sum is a select.
+template <typename TX, int VEC, int TEAM, int NV>
+__device__ __forceinline__ void masked_scores_pack(const SmArgs& a, const RowTile<TX, VEC, TEAM, NV>& x,
+                                                   const MaskTile<VEC, TEAM, NV>& mt, int k, float (&v)[VEC]) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        float t = rnd<TX>(to_f<TX>(x.v[k].e[e]) * a.inv_div);
+        t = t + mt.m[k][e];
+        if constexpr (sizeof(TX) == 2) {
+            const float th = rnd<__half>(t);
+            t = a.sum_half ? th : t;
+        }
+        v[e] = t;
+    }
+}
+template <typename TX, int VEC, int TEAM, int NV>
+__device__ __forceinline__ void masked_scores(const SmArgs& a, const RowTile<TX, VEC, TEAM, NV>& x, const MaskTile<VEC, TEAM, NV>& mt,
+                                              float (&v)[NV][VEC]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (!x.has(k)) continue;
+        masked_scores_pack(a, x, mt, k, v[k]);
+    }
+}
+
+// Rows of a block.  Plain order: block b holds rows b * RPB ... (one per team).  With a.head_block = HB > 1 (the host sets
+// it when a mask is present, q_len is a multiple of RPB and the head count a multiple of HB) a block holds RPB consecutive
+// query rows of HB consecutive heads: its teams walk the heads one after the other with the mask values in registers.
+// Consecutive blocks still walk consecutive query rows of one head group, so the score traffic keeps its order.
+template <int RPB>
+__device__ __forceinline__ long long block_first_row(const SmArgs& a, long long block) {
+    if (a.head_block <= 1) return block * RPB;
+    const long long qblocks = a.q_len / RPB;
+    const long long groups = a.rows_per_batch / a.q_len / a.head_block;  // head groups per batch entry
+    const long long per_batch = groups * qblocks;
+    const long long batch = block / per_batch, r = block % per_batch;
+    return batch * a.rows_per_batch + (r / qblocks) * a.head_block * a.q_len + (r % qblocks) * RPB;
 }
 
 template <typename TX, int VEC, int TEAM, int NV>
@@ -96,44 +132,55 @@ k_masked_softmax_fwd(SmArgs a, TX* __restrict__ out, float2* __restrict__ row_st
     __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    long long row = block_first_row<RPB>(a, blockIdx.x) + threadIdx.x / TEAM;
     // TEAM > 64 implies RPB == 1: a block is one row, so this exit is block-uniform where barriers follow
     if (row >= a.R) return;
     RowTile<TX, VEC, TEAM, NV> x;
     x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
-    float v[NV][VEC];
-    masked_scores(a, x, row, v);
-    float mx[1] = {-__builtin_inff()};
+    MaskTile<VEC, TEAM, NV> mt;
+    mt.load(a, row, x);
+    for (int hh = 0;;) {
+        float v[NV][VEC];
+        masked_scores(a, x, mt, v);
+        float mx[1] = {-__builtin_inff()};
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            v[k][e] = (v[k][e] < a.floor_) ? a.floor_ : v[k][e];  // torch.max(w, finfo.min): NaN stays NaN
-            mx[0] = nmax(mx[0], v[k][e]);
+            for (int e = 0; e < VEC; ++e) {
+                v[k][e] = (v[k][e] < a.floor_) ? a.floor_ : v[k][e];  // torch.max(w, finfo.min): NaN stays NaN
+                mx[0] = nmax(mx[0], v[k][e]);
+            }
         }
-    }
-    team_reduce<TEAM, 1>(mx, OpMaxNan(), lds);
-    float sum[1] = {0.f};
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            v[k][e] = __expf(v[k][e] - mx[0]);
-            sum[0] += v[k][e];
+        const long long here = row;
+        const bool more = ++hh < a.head_block;
+        if (more) {  // the next head's scores travel while this one is reduced
+            row += a.q_len;
+            x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
         }
-    }
-    team_sum<TEAM, 1>(sum, lds);
-    const float inv = 1.0f / sum[0];
-    if (row_stats && lane == 0) row_stats[row] = make_float2(mx[0], inv);
+        team_reduce<TEAM, 1>(mx, OpMaxNan(), lds);
+        float sum[1] = {0.f};
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
-        Pack<TX, VEC> o;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.e[e] = from_f<TX>(v[k][e] * inv);
-        st_pack<TX, VEC>(out + row * a.C + x.offset(k), o);
+            for (int e = 0; e < VEC; ++e) {
+                v[k][e] = __expf(v[k][e] - mx[0]);
+                sum[0] += v[k][e];
+            }
+        }
+        team_sum<TEAM, 1>(sum, lds);
+        const float inv = 1.0f / sum[0];
+        if (row_stats && lane == 0) row_stats[here] = make_float2(mx[0], inv);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            Pack<TX, VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.e[e] = from_f<TX>(v[k][e] * inv);
+            st_pack<TX, VEC>(out + here * a.C + x.offset(k), o);
+        }
+        if (!more) break;
     }
 }
 
@@ -170,47 +217,89 @@ k_masked_softmax_bwd(const TX* __restrict__ p, const TX* __restrict__ g, TX* __r
     }
 }
 
-// The same from the scores: p = exp(w - max) * (1 / sum) in fp32 exactly as the forward formed it
+// The same from the scores: p = exp(w - max) * (1 / sum) in fp32 exactly as the forward formed it.
+// Gradient of torch.max(w, floor) with respect to w: 1 above the floor, 0 below, 1/2 on a tie (ATen's rule for maximum).
+// It differs from 1 only where w <= floor, and there p = exp(floor - max) is exactly 0 (hence the gradient 0 whatever the
+// factor) unless the row's maximum lies within ~104 of the floor (a row whose every key is masked): such rows take the
+// branch that applies the factor, decided once per row.
 template <typename TX, int VEC, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
 k_masked_softmax_bwd_scores(SmArgs a, const float2* __restrict__ row_stats, const TX* __restrict__ g, TX* __restrict__ dx) {
     __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    long long row = block_first_row<RPB>(a, blockIdx.x) + threadIdx.x / TEAM;
     if (row >= a.R) return;
     RowTile<TX, VEC, TEAM, NV> x, gg;
     x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
     gg.load_nt(g + row * a.C, a.C, lane);
-    const float2 st = row_stats[row];
-    float v[NV][VEC], pass[NV][VEC];
-    masked_scores(a, x, row, v);
-    float dot[1] = {0.f};
+    MaskTile<VEC, TEAM, NV> mt;
+    mt.load(a, row, x);
+    for (int hh = 0;;) {
+        const float2 st = row_stats[row];
+        const bool near_floor = !(st.x - a.floor_ > 128.f);  // also a NaN maximum
+        float v[NV][VEC];
+        masked_scores(a, x, mt, v);
+        float dot[1] = {0.f};
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            // gradient of torch.max(w, floor) with respect to w: 1 above the floor, 0 below, 1/2 on a tie (ATen's rule
-            // for maximum; it only shows in a row whose every key is masked, elsewhere p is 0 at the floor)
-            const float w = v[k][e];
-            pass[k][e] = (w < a.floor_) ? 0.f : (w == a.floor_ ? 0.5f : 1.f);
-            v[k][e] = __expf(((w < a.floor_) ? a.floor_ : w) - st.x) * st.y;
-            dot[0] += v[k][e] * to_f<TX>(gg.v[k].e[e]);
+            for (int e = 0; e < VEC; ++e) {
+                const float w = v[k][e];
+                v[k][e] = __expf(((w < a.floor_) ? a.floor_ : w) - st.x) * st.y;
+                dot[0] += v[k][e] * to_f<TX>(gg.v[k].e[e]);
+            }
         }
-    }
-    team_sum<TEAM, 1>(dot, lds);
+        team_sum<TEAM, 1>(dot, lds);
+        if (near_floor) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
-        Pack<TX, VEC> o;
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+                float w[VEC];
+                masked_scores_pack(a, x, mt, k, w);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float dw = rnd<TX>(v[k][e] * (to_f<TX>(gg.v[k].e[e]) - dot[0]));  // rounded by the softmax's cast
-            o.e[e] = from_f<TX>(rnd<TX>(dw * pass[k][e]) * a.inv_div);
+                for (int e = 0; e < VEC; ++e) {
+                    const float pass = (w[e] < a.floor_) ? 0.f : (w[e] == a.floor_ ? 0.5f : 1.f);
+                    const float dw = rnd<TX>(v[k][e] * (to_f<TX>(gg.v[k].e[e]) - dot[0]));
+                    v[k][e] = rnd<TX>(dw * pass);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    v[k][e] = rnd<TX>(v[k][e] * (to_f<TX>(gg.v[k].e[e]) - dot[0]));  // rounded by the softmax's cast
+            }
         }
-        st_pack<TX, VEC>(dx + row * a.C + x.offset(k), o);
+        const long long here = row;
+        const bool more = ++hh < a.head_block;
+        if (more) {  // the next head's operands travel while this one is stored
+            row += a.q_len;
+            x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
+            gg.load_nt(g + row * a.C, a.C, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            Pack<TX, VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.e[e] = from_f<TX>(v[k][e] * a.inv_div);
+            st_pack<TX, VEC>(dx + here * a.C + x.offset(k), o);
+        }
+        if (!more) break;
     }
+}
+
+// grid of the head-blocked kernels and the head block they use
+template <int RPB>
+static inline unsigned sm_grid(SmArgs& a) {
+    constexpr int HB = 4;
+    const long long heads = a.rows_per_batch / a.q_len;
+    a.head_block = (a.mask && a.q_len % RPB == 0 && heads % HB == 0) ? HB : 1;
+    return (unsigned)((a.R + (long long)RPB * a.head_block - 1) / ((long long)RPB * a.head_block));
 }
 
 template <typename TX>
@@ -219,9 +308,10 @@ static int launch_sm_fwd(const SmArgs& a, void* out, float* row_stats, hipStream
     const int npack = a.C / VEC;
 #define L(TEAM, NV)                                                                                               \
     {                                                                                                             \
-        constexpr int RPB = block_of<TEAM>() / TEAM;                                                              \
-        hipLaunchKernelGGL((k_masked_softmax_fwd<TX, VEC, TEAM, NV>), dim3((unsigned)((a.R + RPB - 1) / RPB)),    \
-                           dim3(block_of<TEAM>()), 0, stream, a, (TX*)out, (float2*)row_stats);                  \
+        SmArgs b = a;                                                                                             \
+        const unsigned grid = sm_grid<block_of<TEAM>() / TEAM>(b);                                                \
+        hipLaunchKernelGGL((k_masked_softmax_fwd<TX, VEC, TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0,      \
+                           stream, b, (TX*)out, (float2*)row_stats);                                              \
     }
     MIQ_ROW_DISPATCH(npack, L);
 #undef L
@@ -251,9 +341,10 @@ static int launch_sm_bwd_scores(const SmArgs& a, const float* row_stats, const v
     const int npack = a.C / VEC;
 #define L(TEAM, NV)                                                                                                  \
     {                                                                                                                \
-        constexpr int RPB = block_of<TEAM>() / TEAM;                                                                 \
-        hipLaunchKernelGGL((k_masked_softmax_bwd_scores<TX, VEC, TEAM, NV>), dim3((unsigned)((a.R + RPB - 1) / RPB)), \
-                           dim3(block_of<TEAM>()), 0, stream, a, (const float2*)row_stats, (const TX*)g, (TX*)dx);   \
+        SmArgs b = a;                                                                                                \
+        const unsigned grid = sm_grid<block_of<TEAM>() / TEAM>(b);                                                   \
+        hipLaunchKernelGGL((k_masked_softmax_bwd_scores<TX, VEC, TEAM, NV>), dim3(grid), dim3(block_of<TEAM>()), 0,  \
+                           stream, b, (const float2*)row_stats, (const TX*)g, (TX*)dx);                              \
     }
     MIQ_ROW_DISPATCH(npack, L);
 #undef L
@@ -283,6 +374,7 @@ static int sm_args(const char* who, const void* x, const void* mask, int64_t R, 
     a.inv_div = 1.0f / div;
     a.floor_ = !mask ? -__builtin_inff() : (a.sum_half ? -65504.0f : -3.4028234663852886e38f);
     a.R = R; a.C = (int)C; a.rows_per_batch = mask ? rows_per_batch : 1; a.q_len = mask ? (int)q_len : 1;
+    a.head_block = 1;
     return 0;
 }
 
