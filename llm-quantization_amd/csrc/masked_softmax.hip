@@ -39,7 +39,9 @@ struct SmArgs {
     int C;
     long long rows_per_batch;  // heads * q_len score rows share one batch entry of the mask
     int q_len;
-    int head_block;      // heads a block walks per query row (set by the launcher)
+    int head_block;      // heads a block walks per query row (set by the launcher, with the two counts below)
+    unsigned qblocks;           // q_len / rows per block
+    unsigned blocks_per_batch;  // (heads / head_block) * qblocks
 };
 
 struct OpMaxNan {
@@ -57,13 +59,12 @@ template <int VEC, int TEAM, int NV>
 struct MaskTile {
     float m[NV][VEC];
     template <typename TX>
-    __device__ __forceinline__ void load(const SmArgs& a, long long row, const RowTile<TX, VEC, TEAM, NV>& geo) {
+    __device__ __forceinline__ void load(const SmArgs& a, long long mrow, const RowTile<TX, VEC, TEAM, NV>& geo) {
 #pragma unroll
         for (int k = 0; k < NV; ++k)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) m[k][e] = 0.f;  // no mask: w + 0 is w
         if (!a.mask) return;
-        const long long mrow = mask_row(a, row);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!geo.has(k)) continue;
@@ -116,14 +117,21 @@ __device__ __forceinline__ void masked_scores(const SmArgs& a, const RowTile<TX,
 // it when a mask is present, q_len is a multiple of RPB and the head count a multiple of HB) a block holds RPB consecutive
 // query rows of HB consecutive heads: its teams walk the heads one after the other with the mask values in registers.
 // Consecutive blocks still walk consecutive query rows of one head group, so the score traffic keeps its order.
+// The position is decomposed from the block index with 32-bit, block-uniform arithmetic; the mask row follows from the
+// parts (a 64-bit division and remainder per thread, as mask_row needs them, are some 300 instructions).
 template <int RPB>
-__device__ __forceinline__ long long block_first_row(const SmArgs& a, long long block) {
-    if (a.head_block <= 1) return block * RPB;
-    const long long qblocks = a.q_len / RPB;
-    const long long groups = a.rows_per_batch / a.q_len / a.head_block;  // head groups per batch entry
-    const long long per_batch = groups * qblocks;
-    const long long batch = block / per_batch, r = block % per_batch;
-    return batch * a.rows_per_batch + (r / qblocks) * a.head_block * a.q_len + (r % qblocks) * RPB;
+__device__ __forceinline__ void block_rows(const SmArgs& a, int team, long long& row, long long& mrow) {
+    if (a.head_block > 1) {
+        const unsigned b = blockIdx.x;
+        const unsigned batch = b / a.blocks_per_batch, r = b % a.blocks_per_batch;
+        const unsigned group = r / a.qblocks, qb = r % a.qblocks;
+        const unsigned q = qb * RPB + team;
+        row = (long long)batch * a.rows_per_batch + (long long)group * a.head_block * a.q_len + q;
+        mrow = (long long)batch * a.q_len + q;
+    } else {
+        row = (long long)blockIdx.x * RPB + team;
+        mrow = (a.mask && row < a.R) ? mask_row(a, row) : 0;
+    }
 }
 
 template <typename TX, int VEC, int TEAM, int NV>
@@ -132,13 +140,14 @@ k_masked_softmax_fwd(SmArgs a, TX* __restrict__ out, float2* __restrict__ row_st
     __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
-    long long row = block_first_row<RPB>(a, blockIdx.x) + threadIdx.x / TEAM;
+    long long row, mrow;
+    block_rows<RPB>(a, threadIdx.x / TEAM, row, mrow);
     // TEAM > 64 implies RPB == 1: a block is one row, so this exit is block-uniform where barriers follow
     if (row >= a.R) return;
     RowTile<TX, VEC, TEAM, NV> x;
     x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
     MaskTile<VEC, TEAM, NV> mt;
-    mt.load(a, row, x);
+    mt.load(a, mrow, x);
     for (int hh = 0;;) {
         float v[NV][VEC];
         masked_scores(a, x, mt, v);
@@ -228,13 +237,14 @@ k_masked_softmax_bwd_scores(SmArgs a, const float2* __restrict__ row_stats, cons
     __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
-    long long row = block_first_row<RPB>(a, blockIdx.x) + threadIdx.x / TEAM;
+    long long row, mrow;
+    block_rows<RPB>(a, threadIdx.x / TEAM, row, mrow);
     if (row >= a.R) return;
     RowTile<TX, VEC, TEAM, NV> x, gg;
     x.load_nt(reinterpret_cast<const TX*>(a.x) + row * a.C, a.C, lane);
     gg.load_nt(g + row * a.C, a.C, lane);
     MaskTile<VEC, TEAM, NV> mt;
-    mt.load(a, row, x);
+    mt.load(a, mrow, x);
     for (int hh = 0;;) {
         const float2 st = row_stats[row];
         const bool near_floor = !(st.x - a.floor_ > 128.f);  // also a NaN maximum
@@ -298,8 +308,16 @@ template <int RPB>
 static inline unsigned sm_grid(SmArgs& a) {
     constexpr int HB = 4;
     const long long heads = a.rows_per_batch / a.q_len;
-    a.head_block = (a.mask && a.q_len % RPB == 0 && heads % HB == 0) ? HB : 1;
-    return (unsigned)((a.R + (long long)RPB * a.head_block - 1) / ((long long)RPB * a.head_block));
+    const long long plain = (a.R + RPB - 1) / RPB;
+    a.head_block = 1; a.qblocks = a.blocks_per_batch = 1;
+    a.qblocks = a.blocks_per_batch = 1;
+    if (a.mask && a.q_len % RPB == 0 && heads % HB == 0 && plain < (1ll << 32)) {
+        a.head_block = HB;
+        a.qblocks = (unsigned)(a.q_len / RPB);
+        a.blocks_per_batch = (unsigned)(heads / HB) * a.qblocks;
+        return (unsigned)(a.R / ((long long)RPB * HB));
+    }
+    return (unsigned)plain;
 }
 
 template <typename TX>

@@ -31,7 +31,8 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, mask in (("fp32 mask", m32), ("fp16 mask", m16), ("no mask", None)):
+z32 = torch.zeros_like(m32)
+for name, mask in (("fp32 mask", m32), ("fp16 mask", m16), ("zero mask", z32), ("no mask", None)):
     xs = scores.clone().requires_grad_(True)
     out = F.MaskedSoftmax.apply(xs, mask, math.sqrt(128.0))
     t_f = timeit(lambda: F.MaskedSoftmax.apply(scores, mask, math.sqrt(128.0)))
