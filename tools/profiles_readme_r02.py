@@ -27,9 +27,10 @@ def main():
     fam = json.load(open(prof + f"{tag}_families.json"))
     fam1 = json.load(open(prof + "r01_h_families.json"))
     L = ["# profiles/\n"]
-    L.append(f"MI355X, gfx950, ROCm 7.2, one GPU.  `{tag}_*` is round 2's final build (`r02_a_*`, `r02_b_*`: earlier states of the round, "
-             "kept for the history: before the statistics-kernel / cluster-kernel / division work, and before the graph-replayed "
-             "calibration step); `r01_*` are round 1's files, described in the second half of this file.  "
+    L.append(f"MI355X, gfx950, ROCm 7.2, one GPU.  `{tag}_*` is round 2's final build (`r02_a_*`, `r02_b_*`, `r02_c_*`: earlier states of the "
+             "round, kept for the history: before the statistics-kernel / cluster-kernel / division work, before the graph-replayed "
+             "calibration step, and before the launch options left the element loops of the fp16 row, exponent, LET and "
+             "attention-score kernels); `r01_*` are round 1's files, described in the second half of this file.  "
              "`tools/collect_on_gpu.sh <dir>` runs every measurement on the GPU box, `tools/collect_profiles.py <dir> <tag>` installs it "
              "here, `tools/profiles_readme_r02.py <tag>` writes this half of the file.\n")
     L.append("## Round 2\n")
