@@ -1,0 +1,141 @@
+"""Seeded random sweep of shapes, bit-widths and options through the row-wise and the activation kernels against the CPU
+oracle: widths that are not a multiple of the 16-byte pack (the scalar tiles), one-row and one-column matrices, every
+tile of the dispatch tables, groups that do not divide the row, cluster layouts with leftovers.  Forward results must be
+the oracle's bits (clip factors handed over pre-activated, as in the other bit-exact tests)."""
+import random
+
+import pytest
+import torch
+
+from helpers import DT, same
+from miq import functional as F
+from miq import synth
+from oracle import miq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+WIDTHS = [1, 3, 8, 17, 64, 100, 255, 256, 520, 768, 1000, 1024, 1028, 2048, 2052, 3072, 4100, 5120, 8192, 11008, 13824]
+
+
+def _cases(n, seed):
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        I = rnd.choice(WIDTHS)
+        Orows = rnd.choice([1, 2, 5, 16, 33, 64]) if I > 4096 else rnd.choice([1, 2, 7, 64, 130, 257])
+        dt = rnd.choice(["f32", "f16"])
+        bits = rnd.choice([2, 3, 4, 5, 6, 8])
+        sym = rnd.random() < 0.4
+        lwc = rnd.random() < 0.6
+        group = rnd.choice([0, 0, 0, 32, 64, 128]) if I >= 64 else 0
+        if group and not lwc and (Orows * I) % group:
+            group = 0  # without LWC the reference cuts the flat buffer into groups and needs it to divide
+        out.append((i, Orows, I, dt, bits, sym, lwc, group))
+    return out
+
+
+@pytest.mark.parametrize("i,Orows,I,dt,bits,sym,lwc,group", _cases(48, 2024))
+def test_uniform_forward_random_case(i, Orows, I, dt, bits, sym, lwc, group):
+    dtype = DT[dt]
+    x = synth.weight(Orows, I, 1000 + i, dtype)
+    rows = Orows * (-(-I // group) if group else 1)
+    up = low = su = sl = None
+    if lwc:
+        up, low = synth.lwc_factors(rows, 2000 + i, dtype)
+        su, sl = torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)
+    # the oracle applies the sigmoid itself; the kernel receives the same values pre-activated
+    r = O.uniform_row(x, bits, sym, up, low, group or None)
+    out, scale, rzp, codes = F.rowquant_uniform_fwd(x.to(DEV), bits, sym, su, sl, group, want_codes=True, preactivated=lwc)
+    assert same(scale.cpu(), r.scale), "scale"
+    assert same(rzp.cpu(), r.rzp), "rounded zero point"
+    assert same(out.cpu(), r.out), "dequantized values"
+    assert torch.equal(codes.cpu().to(torch.int32), torch.nan_to_num(r.codes.float(), nan=0.0).to(torch.int32)), "codes"
+
+
+def _act_cases(n, seed):
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        C = rnd.choice([8, 64, 100, 256, 520, 1000, 1024, 2048, 2752, 4096, 5120])
+        R = rnd.choice([1, 3, 16, 77, 300, 1025])
+        dt = rnd.choice(["f32", "f16"])
+        bits = rnd.choice([3, 4, 6, 8])
+        kind = rnd.choice(["tensor", "equal", "ragged"])
+        if kind == "tensor" or C < 16:
+            counts = None
+        elif kind == "equal":
+            k = rnd.choice([d for d in (2, 4, 5, 8, 10, 16, 32) if C % d == 0] or [1])
+            counts = [C // k] * k
+        else:
+            cuts = sorted(rnd.sample(range(1, C), min(5, C - 1)))
+            counts = [b - a for a, b in zip([0] + cuts[:-1], cuts)]   # the tail past the last cut belongs to no cluster
+        out.append((i, R, C, dt, bits, counts))
+    return out
+
+
+@pytest.mark.parametrize("i,R,C,dt,bits,counts", _act_cases(32, 77))
+def test_activation_forward_random_case(i, R, C, dt, bits, counts):
+    dtype = DT[dt]
+    layout = F.ClusterLayout.get(counts, C, DEV)
+    kw = dict(method="per_cluster" if counts else "per_tensor", metric="minmax", cluster_dim=1 if counts else None,
+              cluster_counts=counts)
+    x = synth.activation((R, C), 3000 + i, dtype)
+    outs, codes, vecs = F.act_fresh_quant_fwd([x.to(DEV)], bits, layout, want_codes=True)
+    ref, ref_codes = O.act_forward(x, O.ActState(), bits, "calibration", **kw)
+    assert same(outs[0].cpu(), ref)
+    assert torch.equal(codes[0].cpu().to(torch.int32), torch.nan_to_num(ref_codes, nan=0.0).to(torch.int32))
+
+
+def _row_cases(n, seed):
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        I = rnd.choice(WIDTHS[2:])
+        Orows = rnd.choice([1, 2, 5, 16, 33]) if I > 4096 else rnd.choice([1, 3, 64, 130])
+        out.append((i, Orows, I, rnd.choice(["f32", "f16"]), rnd.choice([2, 3, 4]), rnd.random() < 0.5, rnd.random() < 0.6))
+    return out
+
+
+@pytest.mark.parametrize("i,Orows,I,dt,bits,sym,lwc", _row_cases(32, 31337))
+def test_exponent_grids_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
+    from test_gpu_rowfamilies import check_exp_forward
+    dtype = DT[dt]
+    x = synth.weight(Orows, I, 4000 + i, dtype)
+    up = low = su = sl = None
+    if lwc:
+        up, low = synth.lwc_factors(Orows, 5000 + i, dtype)
+        su, sl = torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)
+    r2 = O.exp2_row(x, bits, up, low)
+    out2, scale2 = F.rowquant_exp2_fwd(x.to(DEV), bits, su, sl, preactivated=lwc)
+    assert same(scale2.cpu(), r2.scale)
+    check_exp_forward(x, r2.scale, out2, r2.out, 2)
+    r1 = O.exp1_row(x, bits, sym, up, low)
+    out1, scale1, _ = F.rowquant_exp1_fwd(x.to(DEV), bits, sym, su, sl, preactivated=lwc)
+    assert same(scale1.cpu(), r1.scale)
+    check_exp_forward(x, r1.scale, out1, r1.out, 1)
+
+
+@pytest.mark.parametrize("i,Orows,I,dt,bits,sym,lwc", [c for c in _row_cases(40, 4242) if c[3] == "f32" and c[2] % 4 == 0][:16])
+def test_mixed_bit_and_let_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
+    g = synth.gen(6000 + i)
+    x = synth.weight(Orows, I, 6000 + i)
+    up = low = su = sl = None
+    if lwc:
+        up, low = synth.lwc_factors(Orows, 7000 + i)
+        su, sl = torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)
+    nb = synth.mix_bits(Orows, 3.0, 8000 + i)
+    for hard in (False, True):
+        r = O.mix_row(x, nb.clone(), sym, up, low, None, hard, 0.0)
+        out = F.rowquant_mix_fwd(x.to(DEV), nb.reshape(-1).to(DEV), sym, su, sl, 0, hard, 0.0, preactivated=lwc)
+        assert same(out.cpu(), r.out), ("mix", hard)
+    if I <= 16384:
+        cs = torch.rand(I, generator=g) * 2 + 0.25
+        rs = torch.rand(Orows, generator=g) * 2 + 0.25
+        for mode in ("div", "mul"):
+            t = x * cs.view(1, -1)
+            t = t / rs.view(-1, 1) if mode == "div" else t * rs.view(-1, 1)
+            res = O.uniform_row(t, bits + 1, sym, up, low)
+            out, _, scale, rzp = F.let_rowquant_fwd(x.to(DEV), cs.to(DEV), rs.to(DEV), mode == "div", None, su, sl, bits + 1, sym,
+                                                    preactivated=lwc)
+            assert same(scale.cpu(), res.scale) and same(rzp.cpu(), res.rzp) and same(out.cpu(), res.out), ("let", mode)
