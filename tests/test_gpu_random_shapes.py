@@ -113,7 +113,7 @@ def test_exponent_grids_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
     r1 = O.exp1_row(x, bits, sym, up, low)
     out1, scale1, _ = F.rowquant_exp1_fwd(x.to(DEV), bits, sym, su, sl, preactivated=lwc)
     assert same(scale1.cpu(), r1.scale)
-    check_exp_forward(x, r1.scale, out1, r1.out, 1)
+    check_exp_forward(x if sym else x - r1.rzp, r1.scale, out1, r1.out, 1)
 
 
 @pytest.mark.parametrize("i,Orows,I,dt,bits,sym,lwc", [c for c in _row_cases(40, 4242) if c[3] == "f32" and c[2] % 4 == 0][:16])
@@ -139,3 +139,34 @@ def test_mixed_bit_and_let_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
             out, _, scale, rzp = F.let_rowquant_fwd(x.to(DEV), cs.to(DEV), rs.to(DEV), mode == "div", None, su, sl, bits + 1, sym,
                                                     preactivated=lwc)
             assert same(scale.cpu(), res.scale) and same(rzp.cpu(), res.rzp) and same(out.cpu(), res.out), ("let", mode)
+
+
+@pytest.mark.parametrize("I", [2048, 4096, 8192, 11008, 13824, 28672])
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_exponent_grids_backward_at_every_tile(I, dt):
+    """The exponent grids' backward picks its tile from a table of its own for 2-byte elements: one case per tile of both
+    tables, gradients against the oracle's autograd (fp16: the oracle accumulates its row sums in fp16, the kernel in fp32)."""
+    from test_gpu_rowfamilies import chain, masked_rel
+    dtype = DT[dt]
+    Orows = 24
+    x = synth.weight(Orows, I, 9000 + I % 97, dtype)
+    up, low = synth.lwc_factors(Orows, 9100 + I % 97, dtype)
+    w = synth.grad_like(x, 9200 + I % 97)
+    su, sl = torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)
+    tol_x, tol_p = (4e-5, 2e-5) if dt == "f32" else (3e-2, 3e-2)
+    for kind in (2, 1):
+        xg = x.clone().requires_grad_(True)
+        pu, pl = up.clone().requires_grad_(True), low.clone().requires_grad_(True)
+        r = O.exp2_row(xg, 3, pu, pl) if kind == 2 else O.exp1_row(xg, 3, True, pu, pl)
+        g = torch.autograd.grad((r.out * w).sum(), [xg, pu, pl])
+        if kind == 2:
+            out = F.rowquant_exp2_fwd(x.to(DEV), 3, su, sl, preactivated=True)[0]
+            dx, d_su, d_sl = F.rowquant_exp2_bwd(w.to(DEV), x.to(DEV), 3, su, sl, preactivated=True)
+        else:
+            out = F.rowquant_exp1_fwd(x.to(DEV), 3, True, su, sl, preactivated=True)[0]
+            dx, d_su, d_sl = F.rowquant_exp1_bwd(w.to(DEV), x.to(DEV), 3, True, su, sl, preactivated=True)
+        if not same(out.cpu(), r.out.detach()):
+            continue  # a level flipped at a threshold: the gradients of that element differ by construction
+        assert masked_rel(dx, g[0]) <= tol_x, (kind, masked_rel(dx, g[0]))
+        assert masked_rel(chain(d_su, su), g[1]) <= tol_p, (kind, "up", masked_rel(chain(d_su, su), g[1]))
+        assert masked_rel(chain(d_sl, sl), g[2]) <= tol_p, (kind, "low", masked_rel(chain(d_sl, sl), g[2]))
