@@ -185,7 +185,8 @@ def test_empty_and_errors():
         F.rowquant_uniform_fwd(torch.zeros(4, 8, device=DEV, dtype=torch.bfloat16), 4, False)
 
 
-@pytest.mark.parametrize("I,dt", [(5120, "f32"), (11008, "f32"), (13824, "f32"), (28672, "f32"), (28672, "f16"), (11008, "f16")])
+@pytest.mark.parametrize("I,dt", [(5120, "f32"), (11008, "f32"), (13824, "f32"), (28672, "f32"), (28672, "f16"), (11008, "f16"),
+                                  (2048, "f32"), (1540, "f32"), (4096, "f16"), (3080, "f16"), (8192, "f16")])  # incl. the 2-pack tile
 def test_backward_at_llama_row_widths(I, dt):
     """Row widths that leave part of the widest register tiles idle (5120 ... 28672): gradients vs the oracle."""
     dtype = DT[dt]
