@@ -42,6 +42,9 @@ extern "C" {
                                   the flag the kernel evaluates 1/(1+expf(-f)) itself, whose last bit
                                   depends on the math library. */
 
+/* major*10000 + minor*100 + patch of this interface; it grows when an entry point is added or a signature changes
+ * (200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
+ * miq_act_quant_from_table, miq_gather_layernorm_bwd, miq_act_calib_quant_fwd_static) */
 int miq_version(void);
 const char* miq_last_error(void);
 
