@@ -438,6 +438,8 @@ __device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, l
 // ---------------------------------------------------------------------------------------------
 // Host-side launch helper: pick (TEAM, NV) from the number of 16-byte packs in the longest row.
 // ---------------------------------------------------------------------------------------------
+// 11008-wide fp32 rows (2752 packs) take a 6-pack tile on 512 lanes: the 8-pack tile's registers for packs that hold
+// nothing cost the forward kernels 2-3 % (and the LET forward, which keeps three vectors per pack, a third of its time).
 // Teams that are not powers of two (384 x 8 for 11008-wide rows, 320 x 4, 448 x 8, 896 x 8) remove the idle
 // lanes of the next larger tile but were measured slower in the backward kernels (6 or 7 waves per block
 // spread unevenly over the 4 SIMDs), so the table stays with power-of-two teams.
@@ -459,6 +461,7 @@ __device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, l
         } else {                                                         \
             if ((NPACK) <= 1024) { LAUNCH(256, 4); }                     \
             else if ((NPACK) <= 2048) { LAUNCH(256, 8); }                \
+            else if ((NPACK) <= 3072) { LAUNCH(512, 6); }                \
             else if ((NPACK) <= 4096) { LAUNCH(512, 8); }                \
             else { LAUNCH(1024, 8); }                                    \
         }                                                                \
@@ -486,6 +489,7 @@ __device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, l
         } else {                                                                                           \
             if ((NPACK) <= 1024) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 4, GEO, STREAM, __VA_ARGS__)       \
             else if ((NPACK) <= 2048) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 8, GEO, STREAM, __VA_ARGS__)  \
+            else if ((NPACK) <= 3072) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 6, GEO, STREAM, __VA_ARGS__)  \
             else if ((NPACK) <= 4096) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 8, GEO, STREAM, __VA_ARGS__)  \
             else MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 8, GEO, STREAM, __VA_ARGS__)                      \
         }                                                                                                  \
