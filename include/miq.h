@@ -289,6 +289,16 @@ int miq_rowquant_exp2_fwd(const void* x, const void* up, const void* low, void* 
 int miq_rowquant_exp2_bwd(const void* grad_out, const void* x, const void* up, const void* low, void* dx,
                           void* d_up, void* d_low, int64_t O, int64_t I, int64_t group, int n_bits,
                           int flags, int dtype, void* stream);
+/* The same over n (1..16) matrices [O_i, I] of one row width and dtype in one launch each way (whole rows, no groups;
+ * pointer tables like miq_rowquant_uniform_fwd_batch; up / low, dx and d_up / d_low for all matrices or for none).
+ * Results are those of the single-matrix entry points bit for bit.  No counterpart in the reference, which quantizes
+ * the weight matrices of a block one after the other (quantize/int_linear.py:72-87). */
+int miq_rowquant_exp2_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low, void* const* out,
+                                void* const* scale_out, const int64_t* O, int64_t I, int n_bits, int flags, int dtype,
+                                void* stream);
+int miq_rowquant_exp2_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
+                                const int64_t* O, int64_t I, int n_bits, int flags, int dtype, void* stream);
 
 /*
  * Exponential/log weight quantizer v1 (levels +-2^e, e in [-(2^(n-1)-1), 0], no zero level).

@@ -435,6 +435,31 @@ __device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, l
     d_low[row] = from_f<T>(d_xmin * rmin * jl);
 }
 
+// Several matrices of one row width in ONE launch (the weight matrices of a block are quantized back to
+// back and are independent): a 67 MB matrix alone streams at ~5.0 TB/s because the launch's ramp-up and
+// tail are a sizeable part of its 25 us; 38400 rows in one launch reach 5.7 TB/s.
+constexpr int kMaxBatch = 16;
+template <typename T>
+struct UniBatch {
+    const T* x[kMaxBatch];
+    const T* up[kMaxBatch];
+    const T* low[kMaxBatch];
+    const T* gout[kMaxBatch];   // backward only
+    T* out[kMaxBatch];          // forward: dequantized output; backward: dx (or nullptr)
+    T* a1[kMaxBatch];           // forward: scale; backward: d_up
+    T* a2[kMaxBatch];           // forward: rounded zero point; backward: d_low
+    long long row_start[kMaxBatch + 1];
+    int n;
+};
+
+template <typename T>
+__device__ __forceinline__ int batch_locate(const UniBatch<T>& b, long long row, long long& local) {
+    int m = 0;
+    while (m + 1 < b.n && row >= b.row_start[m + 1]) ++m;
+    local = row - b.row_start[m];
+    return m;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-side launch helper: pick (TEAM, NV) from the number of 16-byte packs in the longest row.
 // ---------------------------------------------------------------------------------------------

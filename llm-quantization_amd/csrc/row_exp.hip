@@ -76,14 +76,10 @@ __device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c, const 
     return r;
 }
 
+// the work of one team on one quantization row
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_exp2_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out) {
-    __shared__ float lds[32];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= geo.n_rows) return;
+__device__ __forceinline__ void exp2_fwd_row(const ExpArgs<T>& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                             T* __restrict__ out, T* __restrict__ scale_out) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -104,20 +100,43 @@ k_exp2_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     }
 }
 
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp2_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    exp2_fwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, out, scale_out);
+}
+
+// several matrices of one row width in one launch (the table of the uniform quantizer's batched kernels)
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp2_fwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    exp2_fwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.out[m], b.a1[m]);
+}
+
 // Reference backward (quantizer_exp_v2.py:65-105), element by element:
 //   gq   = g*s, negated where sign == -1; zeroed where the level saturates, is the zero bin, or
 //          the threshold branch was taken;  grad_q = ((ln2*lvl)*gq / ln2 / mag) * sign
 //   dx   = grad_q / s;   d_scale = g*signed_lvl + grad_q * (-x / s^2)   (summed over the row)
 // followed by autograd through clamp(scale), max(|xmax|,|xmin|), the sigmoid clipping and amax/amin.
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
-           T* __restrict__ d_low) {
-    __shared__ float lds[64];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= geo.n_rows) return;
+__device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                             const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
+                                             T* __restrict__ d_low) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -194,6 +213,34 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
             st_pack<T, VEC>(dx + base + x.offset(k), o);
         }
     }
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
+           T* __restrict__ d_low) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    exp2_bwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, gout, dx, d_up, d_low);
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp2_bwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    exp2_bwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.gout[m], b.out[m], b.a1[m], b.a2[m]);
 }
 
 // ------------------------------------------------------------------------------------------ v1
@@ -406,6 +453,87 @@ static int launch_exp(int which, bool backward, const void* gout, const void* x,
     return 0;
 }
 
+// v2 over several matrices of one row width (whole rows, no groups): one launch each way
+template <typename T>
+static int launch_exp2_batch(bool backward, int n, const void* const* gout, const void* const* x, const void* const* up,
+                             const void* const* low, void* const* out_or_dx, void* const* a1, void* const* a2, const int64_t* O,
+                             long long I, int n_bits, int flags, hipStream_t stream) {
+    const char* name = backward ? "miq_rowquant_exp2_bwd_batch" : "miq_rowquant_exp2_fwd_batch";
+    if (n == 0 || I == 0) return 0;
+    MIQ_CHECK_ARG(n > 0 && n <= kMaxBatch && x && O && I > 0 && I < (1ll << 31), "%s: 1..%d matrices of one width expected", name, kMaxBatch);
+    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 4, "%s: n_bits=%d outside [2,4]", name, n_bits);
+    MIQ_CHECK_ARG(backward ? (gout != nullptr) : (out_or_dx && a1), "%s: null pointer table", name);
+    constexpr int N = VecOf<T>::N;
+    UniBatch<T> b{};
+    const bool lwc = up != nullptr && up[0] != nullptr;
+    const bool want_dx = backward && out_or_dx != nullptr && out_or_dx[0] != nullptr;
+    MIQ_CHECK_ARG(!backward || !lwc || (a1 && a2), "%s: d_up/d_low tables required when up/low are given", name);
+    bool vec_ok = (I % N == 0);
+    long long rows = 0;
+    b.n = 0;
+    for (int i = 0; i < n; ++i) {
+        MIQ_CHECK_ARG(O[i] >= 0, "%s: negative row count", name);
+        if (O[i] == 0) continue;
+        const int m = b.n++;
+        b.x[m] = (const T*)x[i];
+        b.up[m] = lwc ? (const T*)up[i] : nullptr;
+        b.low[m] = lwc ? (const T*)low[i] : nullptr;
+        b.gout[m] = backward ? (const T*)gout[i] : nullptr;
+        b.out[m] = (backward && !want_dx) ? nullptr : (T*)out_or_dx[i];
+        b.a1[m] = (backward && !lwc) ? nullptr : (T*)a1[i];
+        b.a2[m] = (backward && lwc) ? (T*)a2[i] : nullptr;
+        MIQ_CHECK_ARG(b.x[m] && (!lwc || (b.up[m] && b.low[m])) && (!backward || b.gout[m]) && (backward || (b.out[m] && b.a1[m])) &&
+                          (!want_dx || b.out[m]) && (!(backward && lwc) || (b.a1[m] && b.a2[m])),
+                      "%s: null pointer in entry %d (LWC and dx must be given for all matrices or for none)", name, i);
+        vec_ok = vec_ok && is_aligned16(b.x[m]) && is_aligned16(b.out[m]) && is_aligned16(b.gout[m]);
+        b.row_start[m] = rows;
+        rows += O[i];
+    }
+    if (b.n == 0) return 0;
+    for (int m = b.n; m <= kMaxBatch; ++m) b.row_start[m] = rows;
+    RowGeom geo;
+    geo.I = (int)I;
+    geo.g = (int)I;
+    geo.G = 1;
+    geo.n_rows = rows;
+    ExpArgs<T> a{};
+    a.n_bits = n_bits;
+    a.symmetric = 1;
+    a.preact = (flags >> 1) & 1;
+    const int npack = vec_ok ? geo.g / N : geo.g;
+    MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
+#define LAUNCH_ONE(KERN, VECN, TEAM, NV)                                                                       \
+    {                                                                                                          \
+        constexpr int B = block_of<TEAM>();                                                                    \
+        const long long nb = (rows + (B / TEAM) - 1) / (B / TEAM);                                             \
+        hipLaunchKernelGGL((KERN<T, VECN, TEAM, NV>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo);      \
+    }
+    if (!backward) {
+        if (vec_ok) {
+#define L(TEAM, NV) LAUNCH_ONE(k_exp2_fwd_batch, N, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        } else {
+#define L(TEAM, NV) LAUNCH_ONE(k_exp2_fwd_batch, 1, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        }
+    } else {
+        if (vec_ok) {
+#define L(TEAM, NV) LAUNCH_ONE(k_exp2_bwd_batch, N, TEAM, NV)
+            MIQ_ROW_DISPATCH_E(sizeof(T), npack, L);
+#undef L
+        } else {
+#define L(TEAM, NV) LAUNCH_ONE(k_exp2_bwd_batch, 1, TEAM, NV)
+            MIQ_ROW_DISPATCH_E(sizeof(T), npack, L);
+#undef L
+        }
+    }
+#undef LAUNCH_ONE
+    MIQ_CHECK_LAUNCH(name);
+    return 0;
+}
+
 }  // namespace miq
 
 #define MIQ_EXP_ENTRY(WHICH, BWD, ...)                                                                      \
@@ -435,4 +563,26 @@ extern "C" int miq_rowquant_exp1_bwd(const void* grad_out, const void* x, const 
                                      void* d_up, void* d_low, int64_t O, int64_t I, int64_t group, int n_bits,
                                      int symmetric, int flags, int dtype, void* stream) {
     MIQ_EXP_ENTRY(1, true, grad_out, x, up, low, dx, d_up, d_low, O, I, group, n_bits, symmetric, flags)
+}
+
+extern "C" int miq_rowquant_exp2_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                                           void* const* out, void* const* scale_out, const int64_t* O, int64_t I, int n_bits,
+                                           int flags, int dtype, void* stream) {
+    if (dtype == MIQ_F32)
+        return miq::launch_exp2_batch<float>(false, n, nullptr, x, up, low, out, scale_out, nullptr, O, I, n_bits, flags, (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return miq::launch_exp2_batch<__half>(false, n, nullptr, x, up, low, out, scale_out, nullptr, O, I, n_bits, flags, (hipStream_t)stream);
+    miq_set_error("miq_rowquant_exp2_fwd_batch: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_rowquant_exp2_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                           const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
+                                           const int64_t* O, int64_t I, int n_bits, int flags, int dtype, void* stream) {
+    if (dtype == MIQ_F32)
+        return miq::launch_exp2_batch<float>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, flags, (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return miq::launch_exp2_batch<__half>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, flags, (hipStream_t)stream);
+    miq_set_error("miq_rowquant_exp2_bwd_batch: unsupported dtype %d", dtype);
+    return -22;
 }

@@ -140,16 +140,25 @@ class _BlockBase(nn.Module):
             m.weight_quantizer.round_nbits()
 
     def _quantize_temp_weights(self):
-        """temp_weight <- weight_quantizer(temp_weight) for every linear.  Linears that use the plain uniform
-        quantizer with the same settings and row width share one kernel launch."""
+        """temp_weight <- weight_quantizer(temp_weight) for every linear.  Linears that use the plain uniform quantizer
+        (or the exponent quantizer v2) with the same settings and row width share one kernel launch."""
         from . import functional as F
         from .quantizer import UniformAffineQuantizer
-        groups, rest = {}, []
+        from .quantizer_exp_v2 import ExpAffineQuantizer as Exp2Quantizer
+        groups, exp_groups, rest = {}, {}, []
         for _n, m in self.quant_linears():
             src = m.temp_weight if hasattr(m, "temp_weight") else m.weight
             q = m.weight_quantizer
             if self._half_weight_path(q, src):
                 m.temp_weight, _ = q.forward_let(src)
+                continue
+            if not self.batch_weights:
+                rest.append((m, src))
+                continue
+            if (type(q) is Exp2Quantizer and getattr(q, "enable", True) and 2 <= q.n_bits <= 4 and not q.group_size and src.is_cuda
+                    and src.dim() == 2 and src.dtype in (torch.float32, torch.float16)
+                    and (not q.lwc or q.upbound_factor.dtype == src.dtype)):
+                exp_groups.setdefault((src.shape[1], src.dtype, q.n_bits, bool(q.lwc)), []).append((m, src))
                 continue
             if (type(q) is UniformAffineQuantizer and q.enable and q.n_bits < 16 and q.metric != "fix0to1" and q.dynamic
                     and q.dynamic_method in ("per_token", "per_channel") and not q.group_size and src.is_cuda and src.dim() == 2
@@ -172,12 +181,28 @@ class _BlockBase(nn.Module):
                 m.temp_weight = res[3 * j]
                 m.weight_quantizer.scale = res[3 * j + 1]
                 m.weight_quantizer.round_zero_point = res[3 * j + 2]
+        for (_i, _dt, n_bits, lwc), members in exp_groups.items():
+            if len(members) == 1:
+                rest.append(members[0])
+                continue
+            flat = []
+            for m, src in members:
+                flat.append(src)
+                if lwc:
+                    flat += [m.weight_quantizer.upbound_factor, m.weight_quantizer.lowbound_factor]
+            res = F.Exp2RowFQBatch.apply(n_bits, lwc, *flat)
+            for j, (m, _src) in enumerate(members):
+                m.temp_weight = res[2 * j]
+                m.weight_quantizer.scale = res[2 * j + 1]
+                m.weight_quantizer.zero_point = None
         for m, src in rest:
             m.temp_weight = m.weight_quantizer(src)
         for _n, m in self.quant_linears():
             if not hasattr(m, "temp_bias"):
                 m.temp_bias = m.bias
             m.use_temporary_parameter = True
+
+    batch_weights = True  # weight matrices of one width and quantizer setting share one launch each way
 
     half_weights = True  # under fp16 autocast, quantize plain fp32 weights straight into the fp16 tensor the linear uses
 

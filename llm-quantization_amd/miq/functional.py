@@ -1213,6 +1213,43 @@ def rowquant_exp2_bwd(grad_out, x, n_bits: int, up=None, low=None, group: int = 
     return dx, d_up, d_low
 
 
+def rowquant_exp2_fwd_batch(xs, n_bits: int, ups=None, lows=None, preactivated: bool = False):
+    """The exponent (v2) quantizer over several [O_i, I] matrices of one width and dtype in one launch.
+    Returns (outs, scales) lists; bit-identical to rowquant_exp2_fwd per matrix."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*xs, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows)
+    I = xs[0].shape[1]
+    outs = [torch.empty_like(x) for x in xs]
+    scales = [torch.empty((x.shape[0], 1), dtype=x.dtype, device=dev) for x in xs]
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with L.on_device(dev):
+        L.call("miq_rowquant_exp2_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(outs), _ptr_table(scales), O, L.i64(I), L.i32(int(n_bits)),
+               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+    return outs, scales
+
+
+def rowquant_exp2_bwd_batch(gs, xs, n_bits: int, ups=None, lows=None, want_dx: bool = True, preactivated: bool = False):
+    """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None) lists."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*gs, *xs, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows, gs)
+    I = xs[0].shape[1]
+    dxs = [torch.empty_like(x) for x in xs] if want_dx else None
+    d_ups = [torch.empty_like(u) for u in ups] if lwc else None
+    d_lows = [torch.empty_like(u) for u in lows] if lwc else None
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with L.on_device(dev):
+        L.call("miq_rowquant_exp2_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(dxs) if want_dx else None, _ptr_table(d_ups) if lwc else None,
+               _ptr_table(d_lows) if lwc else None, O, L.i64(I), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)),
+               L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+    return dxs, d_ups, d_lows
+
+
 def rowquant_exp1_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0, preactivated=False):
     """Returns (out, scale[rows,1], mid[rows,1]|None)."""
     dev = L.check_gpu(x, up, low)
@@ -1295,6 +1332,45 @@ class Exp2RowFQ(torch.autograd.Function):
             return (None,) * 5
         dx, d_up, d_low = rowquant_exp2_bwd(g.contiguous(), x, n_bits, up, low, group, want_dx=need_dx)
         return dx, d_up, d_low, None, None
+
+
+class Exp2RowFQBatch(torch.autograd.Function):
+    """apply(n_bits, lwc, x_0, [up_0, low_0,] x_1, ...) -> (out_0, scale_0, out_1, ...): several weight matrices of one
+    width through one forward and one backward launch of the exponent (v2) quantizer."""
+
+    @staticmethod
+    def forward(ctx, n_bits, lwc, *ts):
+        step = 3 if lwc else 1
+        xs = [t.contiguous() for t in ts[0::step]]
+        ups = list(ts[1::step]) if lwc else None
+        lows = list(ts[2::step]) if lwc else None
+        outs, scales = rowquant_exp2_fwd_batch(xs, n_bits, ups, lows)
+        ctx.cfg = (n_bits, lwc, len(xs))
+        ctx.save_for_backward(*xs, *(ups or []), *(lows or []))
+        ret = []
+        for o, s in zip(outs, scales):
+            ret += [o, s]
+        ctx.mark_non_differentiable(*scales)
+        ctx.set_materialize_grads(False)
+        return tuple(ret)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n_bits, lwc, n = ctx.cfg
+        saved = ctx.saved_tensors
+        xs = list(saved[:n])
+        ups = list(saved[n:2 * n]) if lwc else None
+        lows = list(saved[2 * n:3 * n]) if lwc else None
+        gs = [(g if g is not None else torch.zeros_like(x)).contiguous() for g, x in zip(grads[0::2], xs)]
+        step = 3 if lwc else 1
+        need_dx = any(ctx.needs_input_grad[2 + i * step] for i in range(n))
+        dxs, d_ups, d_lows = rowquant_exp2_bwd_batch(gs, xs, n_bits, ups, lows, want_dx=need_dx)
+        out = [None, None]
+        for i in range(n):
+            out.append(dxs[i] if need_dx else None)
+            if lwc:
+                out += [d_ups[i], d_lows[i]]
+        return tuple(out)
 
 
 class Exp1RowFQ(torch.autograd.Function):

@@ -3,7 +3,8 @@ bit, to one call per matrix — the batch only changes which launch a row belong
 import pytest
 import torch
 
-from helpers import DT
+from helpers import DT, same
+from miq import _lib as L
 from miq import functional as F
 from miq import synth
 
@@ -90,3 +91,81 @@ def test_batch_wrappers_refuse_what_the_kernels_cannot_check():
     for i, fn in enumerate(bad):
         with pytest.raises(MiqError):
             fn()
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("lwc", [True, False])
+def test_exp2_batch_equals_single_matrix_calls(dt, lwc):
+    """The exponent (v2) quantizer over several matrices of one width in one launch each way: the bits of the
+    single-matrix entry points, forward and backward, with and without clipping factors and dx."""
+    dtype = DT[dt]
+    I = 1024
+    rows = [64, 1, 130, 257]
+    xs = [synth.weight(o, I, 70 + i, dtype).to(DEV) for i, o in enumerate(rows)]
+    gs = [synth.grad_like(x.cpu(), 80 + i).to(DEV) for i, x in enumerate(xs)]
+    ups = lows = None
+    if lwc:
+        fac = [synth.lwc_factors(o, 90 + i, dtype) for i, o in enumerate(rows)]
+        ups, lows = [f[0].to(DEV) for f in fac], [f[1].to(DEV) for f in fac]
+    outs, scales = F.rowquant_exp2_fwd_batch(xs, 3, ups, lows)
+    for want_dx in (True, False):
+        dxs, d_ups, d_lows = F.rowquant_exp2_bwd_batch(gs, xs, 3, ups, lows, want_dx=want_dx)
+        for i, x in enumerate(xs):
+            u, l = (ups[i], lows[i]) if lwc else (None, None)
+            o1, s1 = F.rowquant_exp2_fwd(x, 3, u, l)
+            assert same(outs[i].cpu(), o1.cpu()) and same(scales[i].cpu(), s1.cpu())
+            dx1, du1, dl1 = F.rowquant_exp2_bwd(gs[i], x, 3, u, l, want_dx=want_dx)
+            if want_dx:
+                assert same(dxs[i].cpu(), dx1.cpu())
+            else:
+                assert dxs is None
+            if lwc:
+                assert same(d_ups[i].cpu(), du1.cpu()) and same(d_lows[i].cpu(), dl1.cpu())
+    with pytest.raises(L.MiqError):
+        F.rowquant_exp2_fwd_batch([xs[0], xs[1][:, :512].contiguous()], 3)
+
+
+def test_block_with_batched_exponent_weights_trains_like_one_launch_per_matrix():
+    """An OPT-125m shaped block with the exponent (v2) weight quantizer: the calibration step that quantizes the
+    weight matrices of one width in one launch each way ends at the same parameters, bit for bit, as the step that
+    launches per matrix (the batch only changes which launch a row belongs to)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import bench_block
+    from miq import blocks
+    from miq.calibrate import CalibConfig, calibrate_layer
+
+    def one(batched):
+        blocks._BlockBase.batch_weights = batched
+        try:
+            torch.manual_seed(0)
+            args = bench_block.quant_args(wbits=3, abits=8, lwc=True, a_dynamic_method="per_tensor", a_dynamic=False,
+                                          metric="ema_minmax", let=True, weight_exp_quant=True, w_symmetric=True)
+            qlayer, _ = bench_block.synthetic_block("opt-125m", DEV, args)
+            g = torch.Generator(device=DEV).manual_seed(5)
+            inps = torch.randn(3, 128, 768, generator=g, device=DEV)
+            mask = torch.full((128, 128), torch.finfo(torch.float32).min, device=DEV).triu(1).view(1, 1, 128, 128)
+            cfg = CalibConfig(epochs=2, nsamples=3, batch_size=1, let=True, lwc=True, deactive_amp=True, reorder="")
+            prefix = "model.decoder.layers.0"
+            sc = {f"{prefix}.{n}": torch.rand(768, generator=g, device=DEV) * 3 + 0.2 for n in ("self_attn.q_proj", "self_attn.out_proj", "fc1")}
+            sh = {f"{prefix}.{n}": torch.randn(768, generator=g, device=DEV) * 0.1 for n in ("self_attn.q_proj", "self_attn.out_proj", "fc1")}
+            res = calibrate_layer(qlayer, inps, inps.clone(), mask, cfg, sc, sh, prefix, is_llama=False)
+            return {k: v.detach().clone() for k, v in qlayer.named_parameters()}, res
+        finally:
+            blocks._BlockBase.batch_weights = True
+
+    calls = []
+    real = F.rowquant_exp2_fwd_batch
+    F.rowquant_exp2_fwd_batch = lambda xs, *a, **k: (calls.append(len(xs)), real(xs, *a, **k))[1]
+    try:
+        pa, ra = one(True)
+        assert calls and max(calls) >= 4, calls   # q, k, v, out_proj and fc1 share the 768-wide launch
+        n = len(calls)
+        pb, rb = one(False)
+        assert len(calls) == n                    # per-matrix launches only
+    finally:
+        F.rowquant_exp2_fwd_batch = real
+    assert pa.keys() == pb.keys() and len(pa) > 0
+    for k in pa:
+        assert same(pa[k].cpu(), pb[k].cpu()), k

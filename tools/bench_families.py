@@ -131,6 +131,35 @@ def main():
         row_family("C3.exp1_w3_lwc.llama7b", L7, dt,
                    lambda x, g, u, l: F.rowquant_exp1_fwd(x, 3, True, u, l),
                    lambda x, g, u, l: F.rowquant_exp1_bwd(g, x, 3, True, u, l, want_dx=True), res)
+    # C3 through the batched entry points: the seven Llama-2-7B matrices in one launch per row width
+    def c3_batched():
+        es = 4
+        sets = weights(L7, f32, copies_for(L7, es))
+        n = sum(o * i for o, i in L7) * es * len(sets)
+        groups = {}
+        for j, (_o, i) in enumerate(L7):
+            groups.setdefault(i, []).append(j)
+
+        def fwd():
+            for st in sets:
+                for ids in groups.values():
+                    F.rowquant_exp2_fwd_batch([st[j][0] for j in ids], 3, [st[j][2] for j in ids], [st[j][3] for j in ids])
+
+        def bwd():
+            for st in sets:
+                for ids in groups.values():
+                    F.rowquant_exp2_bwd_batch([st[j][1] for j in ids], [st[j][0] for j in ids], 3, [st[j][2] for j in ids],
+                                              [st[j][3] for j in ids])
+
+        for tag, fn, mult in (("fwd", fwd, 2), ("bwd", bwd, 3)):
+            t = time_graph(fn)
+            gbs = mult * n / t / 1e9
+            res[f"C3.exp2_w3_lwc.llama7b.batched.{tag}.f32"] = {"GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK, 4),
+                                                               "us_per_matrix_set": round(t / len(sets) * 1e6, 1)}
+        del sets
+        torch.cuda.empty_cache()
+
+    c3_batched()
     # C4
     bits = {}
 
