@@ -212,7 +212,8 @@ class Workload:
 
 L13 = [("q", 5120, 5120), ("k", 5120, 5120), ("v", 5120, 5120), ("o", 5120, 5120), ("gate", 13824, 5120), ("up", 13824, 5120),
        ("down", 5120, 13824)]
-C4_KERNEL = {"mix_soft_fwd": "k_mix_fwd", "mix_soft_bwd": "k_mix_bwd", "mix_hard_fwd": "k_mix_fwd", "mix_hard_bwd": "k_mix_bwd",
+C4_KERNEL = {"mix_soft_fwd": "k_mix_fwd_batch", "mix_soft_bwd": "k_mix_bwd_batch", "mix_hard_fwd": "k_mix_fwd_batch",
+             "mix_hard_bwd": "k_mix_bwd_batch",
              "mix2_fwd": "k_uniform_fwd", "mix2_bwd": "k_uniform_bwd", "all_gather": "RCCL all-gather (not a kernel of this library)"}
 
 
@@ -249,6 +250,10 @@ class C4Workload:
               "mix2_bwd": 3 * n}
         return by
 
+    def launches(self, family):
+        """Launches per step: the learnable mixed-bit families take one per row width, the fixed ones one per matrix."""
+        return len({c for _n, _o, c in L13}) if family.startswith("mix_") else len(L13)
+
     def gather_bytes_in(self):
         """Bytes that arrive at every rank in the all-gather of one step."""
         w = self.ctx.world
@@ -257,13 +262,21 @@ class C4Workload:
     def families(self):
         ids = range(len(L13))
 
+        # matrices of one row width go through one launch each way (6 x [*, 5120] and 1 x [5120, 13824])
+        by_width = {}
+        for i, (_n, _o, c) in enumerate(L13):
+            by_width.setdefault(c, []).append(i)
+        self.w_groups = list(by_width.values())
+
         def mix(hard, bwd):
             def run():
-                for i in ids:
+                for grp in self.w_groups:
+                    sel = lambda ts: [ts[i] for i in grp]
                     if bwd:
-                        F.rowquant_mix_bwd(self.g[i], self.w[i], self.bits[i], False, self.up[i], self.low[i], hard=hard, want_dx=True)
+                        F.rowquant_mix_bwd_batch(sel(self.g), sel(self.w), sel(self.bits), False, sel(self.up), sel(self.low),
+                                                 hard=hard, want_dx=True)
                     else:
-                        F.rowquant_mix_fwd(self.w[i], self.bits[i], False, self.up[i], self.low[i], hard=hard)
+                        F.rowquant_mix_fwd_batch(sel(self.w), sel(self.bits), False, sel(self.up), sel(self.low), hard=hard)
             return run
 
         def mix2_fwd():
@@ -338,7 +351,7 @@ def run_c4(args, world, rank, dev, rehearsal, barrier):
     # rank 0's own kernels move 1/world of the layer: per-rank GB/s against this GPU's HBM peak
     fam = {k: {"kernel": C4_KERNEL[k], "GBps_per_rank": round(by[k] / world * args.steps / (totals[k] * 1e-3) / 1e9, 1),
                "frac_hbm_peak": round(by[k] / world * args.steps / (totals[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": len(L13)} for k in by}
+               "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": wl.launches(k)} for k in by}
     if world > 1:
         ms = totals["all_gather"] / args.steps
         fam["all_gather"] = {"kernel": C4_KERNEL["all_gather"], "ms_per_step": round(ms, 4),
@@ -372,8 +385,8 @@ def run_c4(args, world, rank, dev, rehearsal, barrier):
         "frac_hbm_peak": round(step_bytes / world * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": C4_KERNEL[dom], "family": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-                     "bytes_per_launch": by[dom] // world // len(L13),
-                     "avg_launch_us": round(totals[dom] * 1e3 / (len(L13) * args.steps), 2)},
+                     "bytes_per_launch": by[dom] // world // wl.launches(dom),
+                     "avg_launch_us": round(totals[dom] * 1e3 / (wl.launches(dom) * args.steps), 2)},
         "families": fam,
     }
     print(json.dumps(out))

@@ -327,6 +327,17 @@ int miq_rowquant_mix_bwd(const void* grad_out, const void* x, const void* up, co
                          const float* n_bits, void* dx, void* d_up, void* d_low, void* d_nbits, int64_t O,
                          int64_t I, int64_t group, int symmetric, int hard, float threshold, int flags,
                          int dtype, void* stream);
+/* The same over n (1..16) matrices [O_i, I] of one row width in one launch each way (whole rows, no groups; pointer
+ * tables like miq_rowquant_uniform_fwd_batch, n_bits[i] / d_nbits[i] holding O_i entries; up / low, dx and d_nbits for
+ * all matrices or for none).  Results are those of the single-matrix entry points bit for bit.  No counterpart in
+ * the reference, which quantizes the weight matrices of a layer one after the other (quantize/int_linear.py:72-87). */
+int miq_rowquant_mix_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                               const float* const* n_bits, void* const* out, const int64_t* O, int64_t I, int symmetric,
+                               int hard, float threshold, int flags, int dtype, void* stream);
+int miq_rowquant_mix_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                               const void* const* low, const float* const* n_bits, void* const* dx, void* const* d_up,
+                               void* const* d_low, void* const* d_nbits, const int64_t* O, int64_t I, int symmetric,
+                               int hard, float threshold, int flags, int dtype, void* stream);
 
 /*
  * RPTQ reorder index: per head, ascending stable argsort of (xmax - xmin), offset by the head start

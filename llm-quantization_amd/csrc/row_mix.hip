@@ -82,14 +82,10 @@ __device__ __forceinline__ float grid_fq(float xv, const Grid& gr) {
     return (clampf(grid_level(xv, gr), 0.f, gr.Q) - gr.z) * gr.s;
 }
 
+// the work of one team on one quantization row
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_mix_fwd(MixArgs a, RowGeom geo, float* __restrict__ out) {
-    __shared__ float lds[32];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= geo.n_rows) return;
+__device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                            float* __restrict__ out) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -113,13 +109,43 @@ k_mix_fwd(MixArgs a, RowGeom geo, float* __restrict__ out) {
 
 template <typename T, int VEC, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
-k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restrict__ dx, float* __restrict__ d_up,
-          float* __restrict__ d_low, float* __restrict__ d_nbits) {
-    __shared__ float lds[96];
+k_mix_fwd(MixArgs a, RowGeom geo, float* __restrict__ out) {
+    __shared__ float lds[32];
     constexpr int RPB = block_of<TEAM>() / TEAM;
     const int lane = threadIdx.x % TEAM;
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
     if (row >= geo.n_rows) return;
+    mix_fwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, out);
+}
+
+// per-matrix bit-width vectors of a batched launch (the other tables are the uniform quantizer's)
+struct MixBatchBits {
+    const float* n_bits[kMaxBatch];
+    float* d_nbits[kMaxBatch];  // backward only; nullptr: not wanted
+};
+
+// several matrices of one row width in one launch
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_mix_fwd_batch(UniBatch<float> b, MixBatchBits nb, MixArgs a, RowGeom geo) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    a.n_bits = nb.n_bits[m];
+    mix_fwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.out[m]);
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                            const float* __restrict__ gout, float* __restrict__ dx, float* __restrict__ d_up,
+                                            float* __restrict__ d_low, float* __restrict__ d_nbits) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -206,6 +232,35 @@ k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restr
     }
 }
 
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restrict__ dx, float* __restrict__ d_up,
+          float* __restrict__ d_low, float* __restrict__ d_nbits) {
+    __shared__ float lds[96];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    mix_bwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, gout, dx, d_up, d_low, d_nbits);
+}
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_mix_bwd_batch(UniBatch<float> b, MixBatchBits nb, MixArgs a, RowGeom geo) {
+    __shared__ float lds[96];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    a.n_bits = nb.n_bits[m];
+    mix_bwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.gout[m], b.out[m], b.a1[m], b.a2[m], nb.d_nbits[m]);
+}
+
 static int launch_mix(bool backward, const void* gout, const void* x, const void* up, const void* low, const float* n_bits,
                       void* out_or_dx, void* d_up, void* d_low, void* d_nbits, long long O, long long I, long long group,
                       int symmetric, int hard, float threshold, int flags, hipStream_t stream) {
@@ -236,7 +291,111 @@ static int launch_mix(bool backward, const void* gout, const void* x, const void
     return 0;
 }
 
+// several matrices of one row width (whole rows, no groups): one launch each way
+static int launch_mix_batch(bool backward, int n, const void* const* gout, const void* const* x, const void* const* up,
+                            const void* const* low, const float* const* n_bits, void* const* out_or_dx, void* const* d_up,
+                            void* const* d_low, void* const* d_nbits, const int64_t* O, long long I, int symmetric, int hard,
+                            float threshold, int flags, hipStream_t stream) {
+    const char* name = backward ? "miq_rowquant_mix_bwd_batch" : "miq_rowquant_mix_fwd_batch";
+    if (n == 0 || I == 0) return 0;
+    MIQ_CHECK_ARG(n > 0 && n <= kMaxBatch && x && n_bits && O && I > 0 && I < (1ll << 31), "%s: 1..%d matrices of one width expected", name,
+                  kMaxBatch);
+    MIQ_CHECK_ARG((up == nullptr) == (low == nullptr), "%s: up/low tables must both be given or both be null", name);
+    MIQ_CHECK_ARG(backward ? (gout != nullptr) : (out_or_dx != nullptr), "%s: null pointer table", name);
+    UniBatch<float> b{};
+    MixBatchBits nb{};
+    const bool lwc = up != nullptr && up[0] != nullptr;
+    const bool want_dx = backward && out_or_dx != nullptr && out_or_dx[0] != nullptr;
+    const bool want_dn = backward && d_nbits != nullptr && d_nbits[0] != nullptr;
+    MIQ_CHECK_ARG(!backward || !lwc || (d_up && d_low), "%s: d_up/d_low tables required when up/low are given", name);
+    bool vec_ok = (I % 4 == 0);
+    long long rows = 0;
+    b.n = 0;
+    for (int i = 0; i < n; ++i) {
+        MIQ_CHECK_ARG(O[i] >= 0, "%s: negative row count", name);
+        if (O[i] == 0) continue;
+        const int m = b.n++;
+        b.x[m] = (const float*)x[i];
+        b.up[m] = lwc ? (const float*)up[i] : nullptr;
+        b.low[m] = lwc ? (const float*)low[i] : nullptr;
+        b.gout[m] = backward ? (const float*)gout[i] : nullptr;
+        b.out[m] = (backward && !want_dx) ? nullptr : (float*)out_or_dx[i];
+        b.a1[m] = (backward && lwc) ? (float*)d_up[i] : nullptr;
+        b.a2[m] = (backward && lwc) ? (float*)d_low[i] : nullptr;
+        nb.n_bits[m] = n_bits[i];
+        nb.d_nbits[m] = want_dn ? (float*)d_nbits[i] : nullptr;
+        MIQ_CHECK_ARG(b.x[m] && nb.n_bits[m] && (!lwc || (b.up[m] && b.low[m])) && (!backward || b.gout[m]) && (backward || b.out[m]) &&
+                          (!want_dx || b.out[m]) && (!(backward && lwc) || (b.a1[m] && b.a2[m])) && (!want_dn || nb.d_nbits[m]),
+                      "%s: null pointer in entry %d (LWC, dx and d_nbits must be given for all matrices or for none)", name, i);
+        vec_ok = vec_ok && is_aligned16(b.x[m]) && is_aligned16(b.out[m]) && is_aligned16(b.gout[m]);
+        b.row_start[m] = rows;
+        rows += O[i];
+    }
+    if (b.n == 0) return 0;
+    for (int m = b.n; m <= kMaxBatch; ++m) b.row_start[m] = rows;
+    RowGeom geo;
+    geo.I = (int)I;
+    geo.g = (int)I;
+    geo.G = 1;
+    geo.n_rows = rows;
+    MixArgs a{};
+    a.symmetric = symmetric;
+    a.hard = hard;
+    a.threshold = threshold;
+    a.preact = (flags >> 1) & 1;
+    const int npack = vec_ok ? geo.g / 4 : geo.g;
+    MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
+#define LAUNCH_ONE(KERN, VECN, TEAM, NV)                                                                          \
+    {                                                                                                             \
+        constexpr int B = block_of<TEAM>();                                                                       \
+        const long long nblk = (rows + (B / TEAM) - 1) / (B / TEAM);                                              \
+        hipLaunchKernelGGL((KERN<float, VECN, TEAM, NV>), dim3((unsigned)nblk), dim3(B), 0, stream, b, nb, a, geo); \
+    }
+    if (!backward) {
+        if (vec_ok) {
+#define L(TEAM, NV) LAUNCH_ONE(k_mix_fwd_batch, 4, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        } else {
+#define L(TEAM, NV) LAUNCH_ONE(k_mix_fwd_batch, 1, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        }
+    } else {
+        if (vec_ok) {
+#define L(TEAM, NV) LAUNCH_ONE(k_mix_bwd_batch, 4, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        } else {
+#define L(TEAM, NV) LAUNCH_ONE(k_mix_bwd_batch, 1, TEAM, NV)
+            MIQ_ROW_DISPATCH(npack, L);
+#undef L
+        }
+    }
+#undef LAUNCH_ONE
+    MIQ_CHECK_LAUNCH(name);
+    return 0;
+}
+
 }  // namespace miq
+
+extern "C" int miq_rowquant_mix_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                                          const float* const* n_bits, void* const* out, const int64_t* O, int64_t I,
+                                          int symmetric, int hard, float threshold, int flags, int dtype, void* stream) {
+    MIQ_CHECK_ARG(dtype == MIQ_F32, "miq_rowquant_mix_fwd_batch: float32 only");
+    return miq::launch_mix_batch(false, n, nullptr, x, up, low, n_bits, out, nullptr, nullptr, nullptr, O, I, symmetric, hard,
+                                 threshold, flags, (hipStream_t)stream);
+}
+
+extern "C" int miq_rowquant_mix_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                          const void* const* low, const float* const* n_bits, void* const* dx,
+                                          void* const* d_up, void* const* d_low, void* const* d_nbits, const int64_t* O,
+                                          int64_t I, int symmetric, int hard, float threshold, int flags, int dtype,
+                                          void* stream) {
+    MIQ_CHECK_ARG(dtype == MIQ_F32, "miq_rowquant_mix_bwd_batch: float32 only");
+    return miq::launch_mix_batch(true, n, grad_out, x, up, low, n_bits, dx, d_up, d_low, d_nbits, O, I, symmetric, hard,
+                                 threshold, flags, (hipStream_t)stream);
+}
 
 extern "C" int miq_rowquant_mix_fwd(const void* x, const void* up, const void* low, const float* n_bits, void* out,
                                     int64_t O, int64_t I, int64_t group, int symmetric, int hard, float threshold,

@@ -141,11 +141,13 @@ class _BlockBase(nn.Module):
 
     def _quantize_temp_weights(self):
         """temp_weight <- weight_quantizer(temp_weight) for every linear.  Linears that use the plain uniform quantizer
-        (or the exponent quantizer v2) with the same settings and row width share one kernel launch."""
+        (the exponent quantizer v2, the learnable mixed-bit quantizer) with the same settings and row width share one
+        kernel launch."""
         from . import functional as F
         from .quantizer import UniformAffineQuantizer
         from .quantizer_exp_v2 import ExpAffineQuantizer as Exp2Quantizer
-        groups, exp_groups, rest = {}, {}, []
+        from .quantizer_mix import MixAffineQuantizer
+        groups, exp_groups, mix_groups, rest = {}, {}, {}, []
         for _n, m in self.quant_linears():
             src = m.temp_weight if hasattr(m, "temp_weight") else m.weight
             q = m.weight_quantizer
@@ -159,6 +161,11 @@ class _BlockBase(nn.Module):
                     and src.dim() == 2 and src.dtype in (torch.float32, torch.float16)
                     and (not q.lwc or q.upbound_factor.dtype == src.dtype)):
                 exp_groups.setdefault((src.shape[1], src.dtype, q.n_bits, bool(q.lwc)), []).append((m, src))
+                continue
+            if (type(q) is MixAffineQuantizer and not q.group_size and src.is_cuda and src.dim() == 2
+                    and src.dtype == torch.float32 and q.n_bits.dtype == torch.float32):
+                key = (src.shape[1], bool(q.symmetric), bool(q.hard_assign), float(q.threshold), bool(q.lwc))
+                mix_groups.setdefault(key, []).append((m, src))
                 continue
             if (type(q) is UniformAffineQuantizer and q.enable and q.n_bits < 16 and q.metric != "fix0to1" and q.dynamic
                     and q.dynamic_method in ("per_token", "per_channel") and not q.group_size and src.is_cuda and src.dim() == 2
@@ -195,6 +202,22 @@ class _BlockBase(nn.Module):
                 m.temp_weight = res[2 * j]
                 m.weight_quantizer.scale = res[2 * j + 1]
                 m.weight_quantizer.zero_point = None
+        for (_i, sym, hard, threshold, lwc), members in mix_groups.items():
+            if len(members) == 1:
+                rest.append(members[0])
+                continue
+            flat = []
+            for m, src in members:
+                q = m.weight_quantizer
+                q.shape = src.shape
+                if isinstance(q.n_bits, torch.nn.Parameter):
+                    q.n_bits.data = q.n_bits.data.clamp(2, 8)  # as MixAffineQuantizer.forward does before use
+                flat += [src, q.n_bits]
+                if lwc:
+                    flat += [q.upbound_factor, q.lowbound_factor]
+            res = F.MixRowFQBatch.apply(sym, hard, threshold, lwc, *flat)
+            for j, (m, _src) in enumerate(members):
+                m.temp_weight = res[j]
         for m, src in rest:
             m.temp_weight = m.weight_quantizer(src)
         for _n, m in self.quant_linears():

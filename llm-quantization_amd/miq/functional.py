@@ -1312,6 +1312,56 @@ def rowquant_mix_bwd(grad_out, x, n_bits_rows, symmetric: bool, up=None, low=Non
     return dx, d_up, d_low, d_n
 
 
+def _check_mix_batch(xs, bits):
+    if len(bits) != len(xs):
+        raise L.MiqError(f"{len(bits)} bit-width vectors for {len(xs)} matrices")
+    for x, nb in zip(xs, bits):
+        if x.dtype != torch.float32 or nb.dtype != torch.float32:
+            raise L.MiqError("the learnable mixed-bit quantizer is float32 only")
+        if nb.numel() != x.shape[0] or not nb.is_contiguous():
+            raise L.MiqError(f"every n_bits vector must be a contiguous tensor of {x.shape[0]} entries")
+
+
+def rowquant_mix_fwd_batch(xs, bits, symmetric: bool, ups=None, lows=None, hard=False, threshold=0.0, preactivated=False):
+    """The learnable mixed-bit quantizer over several [O_i, I] fp32 matrices of one width in one launch.
+    Returns the list of outputs; bit-identical to rowquant_mix_fwd per matrix."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*xs, *bits, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows)
+    _check_mix_batch(xs, bits)
+    outs = [torch.empty_like(x) for x in xs]
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with L.on_device(dev):
+        L.call("miq_rowquant_mix_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(bits), _ptr_table(outs), O, L.i64(xs[0].shape[1]),
+               L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)), L.i32(_flags(False, preactivated)),
+               L.i32(L.F32), L.stream_of(xs[0]))
+    return outs
+
+
+def rowquant_mix_bwd_batch(gs, xs, bits, symmetric: bool, ups=None, lows=None, hard=False, threshold=0.0, want_dx=True,
+                           preactivated=False):
+    """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None, d_bits) lists."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*gs, *xs, *bits, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows, gs)
+    _check_mix_batch(xs, bits)
+    dxs = [torch.empty_like(x) for x in xs] if want_dx else None
+    d_ups = [torch.empty_like(u) for u in ups] if lwc else None
+    d_lows = [torch.empty_like(u) for u in lows] if lwc else None
+    d_bits = [torch.empty_like(b) for b in bits]
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with L.on_device(dev):
+        L.call("miq_rowquant_mix_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(bits), _ptr_table(dxs) if want_dx else None,
+               _ptr_table(d_ups) if lwc else None, _ptr_table(d_lows) if lwc else None, _ptr_table(d_bits), O,
+               L.i64(xs[0].shape[1]), L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)),
+               L.i32(_flags(False, preactivated)), L.i32(L.F32), L.stream_of(xs[0]))
+    return dxs, d_ups, d_lows, d_bits
+
+
 class Exp2RowFQ(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, up, low, n_bits, group):
@@ -1414,6 +1464,42 @@ class MixRowFQ(torch.autograd.Function):
         dx, d_up, d_low, d_n = rowquant_mix_bwd(g.contiguous(), x, nb, symmetric, up, low, group, hard, threshold,
                                                 want_dx=ctx.needs_input_grad[0])
         return dx, d_n.reshape(nshape), d_up, d_low, None, None, None, None
+
+
+class MixRowFQBatch(torch.autograd.Function):
+    """apply(symmetric, hard, threshold, lwc, x_0, n_bits_0, [up_0, low_0,] x_1, ...) -> (out_0, out_1, ...): several
+    fp32 weight matrices of one width through one forward and one backward launch of the learnable mixed-bit quantizer."""
+
+    @staticmethod
+    def forward(ctx, symmetric, hard, threshold, lwc, *ts):
+        step = 4 if lwc else 2
+        xs = [t.contiguous() for t in ts[0::step]]
+        params = ts[1::step]
+        bits = [p.detach().reshape(-1).contiguous() for p in params]
+        ups = list(ts[2::step]) if lwc else None
+        lows = list(ts[3::step]) if lwc else None
+        outs = rowquant_mix_fwd_batch(xs, bits, symmetric, ups, lows, hard, threshold)
+        ctx.cfg = (symmetric, hard, threshold, lwc, len(xs), [p.shape for p in params])
+        ctx.save_for_backward(*xs, *bits, *(ups or []), *(lows or []))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        symmetric, hard, threshold, lwc, n, nshapes = ctx.cfg
+        saved = ctx.saved_tensors
+        xs, bits = list(saved[:n]), list(saved[n:2 * n])
+        ups = list(saved[2 * n:3 * n]) if lwc else None
+        lows = list(saved[3 * n:4 * n]) if lwc else None
+        gs = [(g if g is not None else torch.zeros_like(x)).contiguous() for g, x in zip(grads, xs)]
+        step = 4 if lwc else 2
+        need_dx = any(ctx.needs_input_grad[4 + i * step] for i in range(n))
+        dxs, d_ups, d_lows, d_bits = rowquant_mix_bwd_batch(gs, xs, bits, symmetric, ups, lows, hard, threshold, want_dx=need_dx)
+        out = [None, None, None, None]
+        for i in range(n):
+            out += [dxs[i] if need_dx else None, d_bits[i].reshape(nshapes[i])]
+            if lwc:
+                out += [d_ups[i], d_lows[i]]
+        return tuple(out)
 
 
 def reorder_index(xmax, xmin, n_heads: int = 1):

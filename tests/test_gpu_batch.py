@@ -169,3 +169,79 @@ def test_block_with_batched_exponent_weights_trains_like_one_launch_per_matrix()
     assert pa.keys() == pb.keys() and len(pa) > 0
     for k in pa:
         assert same(pa[k].cpu(), pb[k].cpu()), k
+
+
+@pytest.mark.parametrize("sym", [False, True])
+@pytest.mark.parametrize("hard", [False, True])
+@pytest.mark.parametrize("I,rows,lwc", [
+    (1024, [64, 1, 130, 257], True),
+    (5120, [40, 3], True),       # Llama-2-13B width
+    (13824, [5, 9], False),      # the 512-lane tile
+    (100, [7, 0, 9], True),      # unaligned rows, an empty matrix
+])
+def test_mix_batch_equals_single_matrix_calls(sym, hard, I, rows, lwc):
+    """The learnable mixed-bit quantizer over several matrices of one width in one launch each way: the bits of the
+    single-matrix entry points (output, dx, d_up / d_low, d n_bits), soft and hard phase."""
+    xs = [synth.weight(o, I, 170 + i).to(DEV) for i, o in enumerate(rows)]
+    gs = [synth.grad_like(x.cpu(), 180 + i).to(DEV) for i, x in enumerate(xs)]
+    bits = [synth.mix_bits(o, 3.0, 190 + i).to(DEV) for i, o in enumerate(rows)]
+    ups = lows = None
+    if lwc:
+        fac = [synth.lwc_factors(o, 200 + i) for i, o in enumerate(rows)]
+        ups, lows = [f[0].to(DEV) for f in fac], [f[1].to(DEV) for f in fac]
+    outs = F.rowquant_mix_fwd_batch(xs, bits, sym, ups, lows, hard=hard, threshold=0.1)
+    for want_dx in (True, False):
+        dxs, d_ups, d_lows, d_bits = F.rowquant_mix_bwd_batch(gs, xs, bits, sym, ups, lows, hard=hard, threshold=0.1,
+                                                              want_dx=want_dx)
+        for i, x in enumerate(xs):
+            if x.shape[0] == 0:
+                continue
+            u, l = (ups[i], lows[i]) if lwc else (None, None)
+            o1 = F.rowquant_mix_fwd(x, bits[i], sym, u, l, hard=hard, threshold=0.1)
+            assert same(outs[i].cpu(), o1.cpu()), i
+            dx1, du1, dl1, dn1 = F.rowquant_mix_bwd(gs[i], x, bits[i], sym, u, l, hard=hard, threshold=0.1, want_dx=want_dx)
+            if want_dx:
+                assert same(dxs[i].cpu(), dx1.cpu()), i
+            else:
+                assert dxs is None
+            assert same(d_bits[i].cpu(), dn1.cpu()), i
+            if lwc:
+                assert same(d_ups[i].cpu(), du1.cpu()) and same(d_lows[i].cpu(), dl1.cpu()), i
+
+
+def test_mix_batch_wrappers_refuse_bad_tables():
+    xs = [synth.weight(r, 64, 3 + i).to(DEV) for i, r in enumerate((8, 16))]
+    bits = [synth.mix_bits(r, 3.0, 5 + i).to(DEV) for i, r in enumerate((8, 16))]
+    gs = [torch.randn_like(x) for x in xs]
+    F.rowquant_mix_fwd_batch(xs, bits, False)
+    bad = [
+        lambda: F.rowquant_mix_fwd_batch(xs, bits[:1], False),
+        lambda: F.rowquant_mix_fwd_batch(xs, [bits[0], bits[0]], False),             # 8 bit-widths for 16 rows
+        lambda: F.rowquant_mix_fwd_batch([x.half() for x in xs], bits, False),
+        lambda: F.rowquant_mix_bwd_batch(gs[:1], xs, bits, False),
+        lambda: F.rowquant_mix_bwd_batch(gs, xs, [b.double() for b in bits], False),
+    ]
+    for fn in bad:
+        with pytest.raises(L.MiqError):
+            fn()
+
+
+def test_mix_batch_autograd_function_equals_per_matrix_function():
+    I = 256
+    rows = (64, 96)
+    xs = [synth.weight(o, I, 220 + i).to(DEV).requires_grad_(True) for i, o in enumerate(rows)]
+    bits = [synth.mix_bits(o, 3.0, 230 + i).to(DEV).requires_grad_(True) for i, o in enumerate(rows)]
+    fac = [synth.lwc_factors(o, 240 + i) for i, o in enumerate(rows)]
+    ups = [f[0].to(DEV).requires_grad_(True) for f in fac]
+    lows = [f[1].to(DEV).requires_grad_(True) for f in fac]
+    flat = []
+    for x, b, u, l in zip(xs, bits, ups, lows):
+        flat += [x, b, u, l]
+    outs = F.MixRowFQBatch.apply(False, False, 0.0, True, *flat)
+    got = torch.autograd.grad(sum((o * o).sum() for o in outs), flat)
+    ref = []
+    for x, b, u, l in zip(xs, bits, ups, lows):
+        o = F.MixRowFQ.apply(x, b, u, l, False, 0, False, 0.0)
+        ref += list(torch.autograd.grad((o * o).sum(), [x, b, u, l]))
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and torch.equal(a, b)

@@ -174,6 +174,37 @@ def main():
         row_family(f"C4.mix_{'hard' if hard else 'soft'}_lwc.llama13b", L13, f32,
                    lambda x, g, u, l: F.rowquant_mix_fwd(x, nb(x, hard), False, u, l, hard=hard),
                    lambda x, g, u, l: F.rowquant_mix_bwd(g, x, nb(x, hard), False, u, l, hard=hard, want_dx=True), res)
+    # C4 through the batched entry points: the seven Llama-2-13B matrices in one launch per row width
+    def c4_batched(hard):
+        es = 4
+        sets = weights(L13, f32, copies_for(L13, es))
+        n = sum(o * i for o, i in L13) * es * len(sets)
+        groups = {}
+        for j, (_o, i) in enumerate(L13):
+            groups.setdefault(i, []).append(j)
+
+        def fwd():
+            for st in sets:
+                for ids in groups.values():
+                    F.rowquant_mix_fwd_batch([st[j][0] for j in ids], [nb(st[j][0], hard) for j in ids], False,
+                                             [st[j][2] for j in ids], [st[j][3] for j in ids], hard=hard)
+
+        def bwd():
+            for st in sets:
+                for ids in groups.values():
+                    F.rowquant_mix_bwd_batch([st[j][1] for j in ids], [st[j][0] for j in ids], [nb(st[j][0], hard) for j in ids],
+                                             False, [st[j][2] for j in ids], [st[j][3] for j in ids], hard=hard)
+
+        for tag, fn, mult in (("fwd", fwd, 2), ("bwd", bwd, 3)):
+            t = time_graph(fn)
+            gbs = mult * n / t / 1e9
+            res[f"C4.mix_{'hard' if hard else 'soft'}_lwc.llama13b.batched.{tag}.f32"] = {
+                "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK, 4), "us_per_matrix_set": round(t / len(sets) * 1e6, 1)}
+        del sets
+        torch.cuda.empty_cache()
+
+    for hard in (False, True):
+        c4_batched(hard)
     fixed = {}
 
     def fb(x):
