@@ -214,7 +214,8 @@ L13 = [("q", 5120, 5120), ("k", 5120, 5120), ("v", 5120, 5120), ("o", 5120, 5120
        ("down", 5120, 13824)]
 C4_KERNEL = {"mix_soft_fwd": "k_mix_fwd_batch", "mix_soft_bwd": "k_mix_bwd_batch", "mix_hard_fwd": "k_mix_fwd_batch",
              "mix_hard_bwd": "k_mix_bwd_batch",
-             "mix2_fwd": "k_uniform_fwd", "mix2_bwd": "k_uniform_bwd", "all_gather": "RCCL all-gather (not a kernel of this library)"}
+             "mix2_fwd": "k_uniform_fwd_bits_batch", "mix2_bwd": "k_uniform_bwd_bits_batch",
+             "all_gather": "RCCL all-gather (not a kernel of this library)"}
 
 
 class C4Workload:
@@ -251,8 +252,8 @@ class C4Workload:
         return by
 
     def launches(self, family):
-        """Launches per step: the learnable mixed-bit families take one per row width, the fixed ones one per matrix."""
-        return len({c for _n, _o, c in L13}) if family.startswith("mix_") else len(L13)
+        """Launches per step: one per row width in every family."""
+        return len({c for _n, _o, c in L13})
 
     def gather_bytes_in(self):
         """Bytes that arrive at every rank in the all-gather of one step."""
@@ -260,8 +261,6 @@ class C4Workload:
         return sum(o * c * 4 for _n, o, c in L13) * (w - 1) // w
 
     def families(self):
-        ids = range(len(L13))
-
         # matrices of one row width go through one launch each way (6 x [*, 5120] and 1 x [5120, 13824])
         by_width = {}
         for i, (_n, _o, c) in enumerate(L13):
@@ -280,12 +279,16 @@ class C4Workload:
             return run
 
         def mix2_fwd():
-            for i in ids:
-                self.deq[i] = F.rowquant_uniform_fwd(self.w[i], 4, False, self.up[i], self.low[i], 0, self.fixed[i], True)[0]
+            for grp in self.w_groups:
+                sel = lambda ts: [ts[i] for i in grp]
+                outs = F.rowquant_mix2_fwd_batch(sel(self.w), sel(self.fixed), False, sel(self.up), sel(self.low))[0]
+                for i, o in zip(grp, outs):
+                    self.deq[i] = o
 
         def mix2_bwd():
-            for i in ids:
-                F.rowquant_uniform_bwd(self.g[i], self.w[i], 4, False, self.up[i], self.low[i], 0, self.fixed[i], True, want_dx=True)
+            for grp in self.w_groups:
+                sel = lambda ts: [ts[i] for i in grp]
+                F.rowquant_mix2_bwd_batch(sel(self.g), sel(self.w), sel(self.fixed), False, sel(self.up), sel(self.low), want_dx=True)
 
         return [("mix_soft_fwd", mix(False, False)), ("mix_soft_bwd", mix(False, True)), ("mix_hard_fwd", mix(True, False)),
                 ("mix_hard_bwd", mix(True, True)), ("mix2_fwd", mix2_fwd), ("mix2_bwd", mix2_bwd)]

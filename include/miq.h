@@ -93,6 +93,17 @@ int miq_rowquant_uniform_bwd_batch(int n, const void* const* grad_out, const voi
                                    const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
                                    const int64_t* O, int64_t I, int n_bits, int symmetric, int flags, int dtype,
                                    void* stream);
+/* The batched launches with per-row integer bit-widths: row_bits[i] holds O_i floats, as the row_bits argument of
+ * miq_rowquant_uniform_fwd (Mix2AffineQuantizer.forward, quantize/quantizer_mix_v2.py:116-146, which clamps the scale:
+ * pass flags bit 0).  Results are those of the single-matrix entry points bit for bit. */
+int miq_rowquant_mix2_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                                const float* const* row_bits, void* const* out, void* const* scale_out,
+                                void* const* rzp_out, const int64_t* O, int64_t I, int symmetric, int flags, int dtype,
+                                void* stream);
+int miq_rowquant_mix2_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                const void* const* low, const float* const* row_bits, void* const* dx, void* const* d_up,
+                                void* const* d_low, const int64_t* O, int64_t I, int symmetric, int flags, int dtype,
+                                void* stream);
 
 /*
  * Static activation quantisation over the channel (last) axis of a row-major [R, C] slab.

@@ -160,6 +160,28 @@ k_uniform_fwd_batch(UniBatch<T> b, UniArgs<T> a, RowGeom geo) {
     uniform_fwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.out[m], b.a1[m], b.a2[m], nullptr);
 }
 
+// per-matrix vectors of per-row bit-widths for the batched launches of the fixed mixed-bit quantizer
+struct BatchBits {
+    const float* p[kMaxBatch];
+};
+
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_uniform_fwd_bits_batch(UniBatch<T> b, BatchBits bits, UniArgs<T> a, RowGeom geo) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    a.row_bits = bits.p[m];
+    uniform_fwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.out[m], b.a1[m], b.a2[m], nullptr);
+}
+
 // Backward.  With m = [0 <= round(x/s)+zp <= qmax] and xd = clamp(..) - zp:
 //   dx      = g*m                       (direct path)
 //   dS      = sum_row g*(xd - m*x/s)    (gradient reaching the scale)
@@ -302,6 +324,23 @@ k_uniform_bwd_batch(UniBatch<T> b, UniArgs<T> a, RowGeom geo) {
     uniform_bwd_row<T, VEC, TEAM, NV, WANT_DX>(a, geo, local, lane, lds, b.gout[m], b.out[m], b.a1[m], b.a2[m]);
 }
 
+template <typename T, int VEC, int TEAM, int NV, bool WANT_DX>
+__global__ void __launch_bounds__(block_of<TEAM>(), (sizeof(T) == 2 && NV == 8 && TEAM < 1024) ? 2 : 4)
+k_uniform_bwd_bits_batch(UniBatch<T> b, BatchBits bits, UniArgs<T> a, RowGeom geo) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    a.row_bits = bits.p[m];
+    uniform_bwd_row<T, VEC, TEAM, NV, WANT_DX>(a, geo, local, lane, lds, b.gout[m], b.out[m], b.a1[m], b.a2[m]);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
@@ -386,14 +425,17 @@ static int launch_uniform(bool backward, const void* gout, const void* x, const 
 template <typename T>
 static int launch_uniform_batch(bool backward, int n, const void* const* gout, const void* const* x, const void* const* up,
                                 const void* const* low, void* const* out_or_dx, void* const* a1, void* const* a2,
-                                const int64_t* O, long long I, int n_bits, int symmetric, int flags, hipStream_t stream) {
-    const char* name = backward ? "miq_rowquant_uniform_bwd_batch" : "miq_rowquant_uniform_fwd_batch";
+                                const int64_t* O, long long I, int n_bits, int symmetric, int flags, hipStream_t stream,
+                                const float* const* row_bits = nullptr) {
+    const char* name = row_bits ? (backward ? "miq_rowquant_mix2_bwd_batch" : "miq_rowquant_mix2_fwd_batch")
+                                : (backward ? "miq_rowquant_uniform_bwd_batch" : "miq_rowquant_uniform_fwd_batch");
     if (n == 0 || I == 0) return 0;
     MIQ_CHECK_ARG(n > 0 && n <= kMaxBatch && x && O && I > 0 && I < (1ll << 31), "%s: 1..%d matrices of one width expected", name, kMaxBatch);
-    MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 15, "%s: n_bits=%d outside [2,15]", name, n_bits);
+    MIQ_CHECK_ARG(row_bits || (n_bits >= 2 && n_bits <= 15), "%s: n_bits=%d outside [2,15]", name, n_bits);
     MIQ_CHECK_ARG(backward ? (gout && a1 && a2) : (out_or_dx && a1 && a2), "%s: null pointer table", name);
     constexpr int N = VecOf<T>::N;
     UniBatch<T> b{};
+    BatchBits bits{};
     const bool lwc = up != nullptr && up[0] != nullptr;
     const bool want_dx = backward && out_or_dx != nullptr && out_or_dx[0] != nullptr;
     bool vec_ok = (I % N == 0);
@@ -413,6 +455,10 @@ static int launch_uniform_batch(bool backward, int n, const void* const* gout, c
         MIQ_CHECK_ARG(b.x[m] && (!lwc || (b.up[m] && b.low[m])) && (!backward || b.gout[m]) && (backward || (b.out[m] && b.a1[m] && b.a2[m])) &&
                           (!want_dx || b.out[m]) && (!(backward && lwc) || (b.a1[m] && b.a2[m])),
                       "%s: null pointer in entry %d (LWC and dx must be given for all matrices or for none)", name, i);
+        if (row_bits) {
+            bits.p[m] = row_bits[i];
+            MIQ_CHECK_ARG(bits.p[m], "%s: null bit-width vector in entry %d", name, i);
+        }
         vec_ok = vec_ok && aligned16(b.x[m]) && aligned16(b.out[m]) && aligned16(b.gout[m]);
         b.row_start[m] = rows;
         rows += O[i];
@@ -425,7 +471,7 @@ static int launch_uniform_batch(bool backward, int n, const void* const* gout, c
     geo.G = 1;
     geo.n_rows = rows;
     UniArgs<T> a{};
-    a.row_bits = nullptr;
+    a.row_bits = nullptr;  // the kernels with bit-width vectors set it per matrix
     a.n_bits = n_bits;
     a.symmetric = symmetric;
     a.clamp_asym = flags & 1;
@@ -436,13 +482,20 @@ static int launch_uniform_batch(bool backward, int n, const void* const* gout, c
     {                                                                                                               \
         constexpr int B = block_of<TEAM>();                                                                         \
         const long long nb = (rows + (B / TEAM) - 1) / (B / TEAM);                                                  \
-        hipLaunchKernelGGL((k_uniform_fwd_batch<T, VECN, TEAM, NV>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo); \
+        if (row_bits)                                                                                               \
+            hipLaunchKernelGGL((k_uniform_fwd_bits_batch<T, VECN, TEAM, NV>), dim3((unsigned)nb), dim3(B), 0, stream, b, bits, a, geo); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_uniform_fwd_batch<T, VECN, TEAM, NV>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo); \
     }
 #define LAUNCH_BWD(VECN, TEAM, NV)                                                                                  \
     {                                                                                                               \
         constexpr int B = block_of<TEAM>();                                                                         \
         const long long nb = (rows + (B / TEAM) - 1) / (B / TEAM);                                                  \
-        if (want_dx)                                                                                                \
+        if (row_bits && want_dx)                                                                                    \
+            hipLaunchKernelGGL((k_uniform_bwd_bits_batch<T, VECN, TEAM, NV, true>), dim3((unsigned)nb), dim3(B), 0, stream, b, bits, a, geo); \
+        else if (row_bits)                                                                                          \
+            hipLaunchKernelGGL((k_uniform_bwd_bits_batch<T, VECN, TEAM, NV, false>), dim3((unsigned)nb), dim3(B), 0, stream, b, bits, a, geo); \
+        else if (want_dx)                                                                                           \
             hipLaunchKernelGGL((k_uniform_bwd_batch<T, VECN, TEAM, NV, true>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo); \
         else                                                                                                        \
             hipLaunchKernelGGL((k_uniform_bwd_batch<T, VECN, TEAM, NV, false>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo); \
@@ -532,5 +585,35 @@ extern "C" int miq_rowquant_uniform_bwd_batch(int n, const void* const* grad_out
         return miq::launch_uniform_batch<__half>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, symmetric, flags,
                                                  (hipStream_t)stream);
     miq_set_error("miq_rowquant_uniform_bwd_batch: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_rowquant_mix2_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                                           const float* const* row_bits, void* const* out, void* const* scale_out,
+                                           void* const* rzp_out, const int64_t* O, int64_t I, int symmetric, int flags,
+                                           int dtype, void* stream) {
+    MIQ_CHECK_ARG(row_bits, "miq_rowquant_mix2_fwd_batch: null bit-width table");
+    if (dtype == MIQ_F32)
+        return miq::launch_uniform_batch<float>(false, n, nullptr, x, up, low, out, scale_out, rzp_out, O, I, 0, symmetric, flags,
+                                                (hipStream_t)stream, row_bits);
+    if (dtype == MIQ_F16)
+        return miq::launch_uniform_batch<__half>(false, n, nullptr, x, up, low, out, scale_out, rzp_out, O, I, 0, symmetric, flags,
+                                                 (hipStream_t)stream, row_bits);
+    miq_set_error("miq_rowquant_mix2_fwd_batch: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_rowquant_mix2_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                           const void* const* low, const float* const* row_bits, void* const* dx,
+                                           void* const* d_up, void* const* d_low, const int64_t* O, int64_t I, int symmetric,
+                                           int flags, int dtype, void* stream) {
+    MIQ_CHECK_ARG(row_bits, "miq_rowquant_mix2_bwd_batch: null bit-width table");
+    if (dtype == MIQ_F32)
+        return miq::launch_uniform_batch<float>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, 0, symmetric, flags,
+                                                (hipStream_t)stream, row_bits);
+    if (dtype == MIQ_F16)
+        return miq::launch_uniform_batch<__half>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, 0, symmetric, flags,
+                                                 (hipStream_t)stream, row_bits);
+    miq_set_error("miq_rowquant_mix2_bwd_batch: unsupported dtype %d", dtype);
     return -22;
 }

@@ -146,6 +146,58 @@ def rowquant_uniform_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, l
     return dxs, d_ups, d_lows
 
 
+def _check_row_bits(xs, row_bits):
+    if len(row_bits) != len(xs):
+        raise L.MiqError(f"{len(row_bits)} bit-width vectors for {len(xs)} matrices")
+    for x, rb in zip(xs, row_bits):
+        if rb.dtype != torch.float32 or rb.numel() != x.shape[0] or not rb.is_contiguous():
+            raise L.MiqError(f"every bit-width vector must be a contiguous float32 tensor of {x.shape[0]} entries")
+
+
+def rowquant_mix2_fwd_batch(xs, row_bits, symmetric: bool, ups=None, lows=None, clamp_asym: bool = True,
+                            preactivated: bool = False):
+    """Row-wise uniform fake quantization with per-row integer bit-widths (the fixed mixed-bit quantizer) of several
+    [O_i, I] matrices of one width and dtype in one launch.  Returns (outs, scales, rzps) lists; bit-identical to
+    rowquant_uniform_fwd(..., row_bits=...) per matrix."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*xs, *row_bits, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows)
+    _check_row_bits(xs, row_bits)
+    outs = [torch.empty_like(x) for x in xs]
+    scales = [torch.empty((x.shape[0], 1), dtype=x.dtype, device=dev) for x in xs]
+    rzps = [torch.empty_like(s) for s in scales]
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with L.on_device(dev):
+        L.call("miq_rowquant_mix2_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(row_bits), _ptr_table(outs), _ptr_table(scales), _ptr_table(rzps), O,
+               L.i64(xs[0].shape[1]), L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)),
+               L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+    return outs, scales, rzps
+
+
+def rowquant_mix2_bwd_batch(gs, xs, row_bits, symmetric: bool, ups=None, lows=None, clamp_asym: bool = True,
+                            want_dx: bool = True, preactivated: bool = False):
+    """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None) lists."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*gs, *xs, *row_bits, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows, gs)
+    _check_row_bits(xs, row_bits)
+    dxs = [torch.empty_like(x) for x in xs] if want_dx else None
+    d_ups = [torch.empty_like(u) for u in ups] if lwc else None
+    d_lows = [torch.empty_like(u) for u in lows] if lwc else None
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    none = [None] * len(xs)
+    with L.on_device(dev):
+        L.call("miq_rowquant_mix2_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(row_bits), _ptr_table(dxs) if want_dx else None,
+               _ptr_table(d_ups if lwc else none), _ptr_table(d_lows if lwc else none), O, L.i64(xs[0].shape[1]),
+               L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)), L.i32(L.dtype_code(xs[0])),
+               L.stream_of(xs[0]))
+    return dxs, d_ups, d_lows
+
+
 class UniformRowFQBatch(torch.autograd.Function):
     """apply(n_bits, symmetric, lwc, x_0, [up_0, low_0,] x_1, ...) -> (out_0, scale_0, rzp_0, out_1, ...):
     several weight matrices of one width through one forward and one backward launch."""

@@ -245,3 +245,40 @@ def test_mix_batch_autograd_function_equals_per_matrix_function():
         ref += list(torch.autograd.grad((o * o).sum(), [x, b, u, l]))
     for a, b in zip(got, ref):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt,I,rows,lwc,sym", [
+    ("f32", 5120, [40, 3, 17], True, False),
+    ("f32", 13824, [5, 9], True, False),
+    ("f16", 1024, [64, 0, 130], True, True),
+    ("f32", 100, [7, 9], False, False),
+])
+def test_mix2_batch_equals_single_matrix_calls(dt, I, rows, lwc, sym):
+    """The fixed mixed-bit quantizer (per-row integer bit-widths, clamped scale) over several matrices of one width in
+    one launch each way: the bits of the single-matrix entry points."""
+    dtype = DT[dt]
+    xs = [synth.weight(o, I, 270 + i, dtype).to(DEV) for i, o in enumerate(rows)]
+    gs = [synth.grad_like(x.cpu(), 280 + i).to(DEV) for i, x in enumerate(xs)]
+    bits = [synth.mix2_bits(o, 290 + i).to(DEV) for i, o in enumerate(rows)]
+    ups = lows = None
+    if lwc:
+        fac = [synth.lwc_factors(o, 300 + i, dtype) for i, o in enumerate(rows)]
+        ups, lows = [f[0].to(DEV) for f in fac], [f[1].to(DEV) for f in fac]
+    outs, scales, rzps = F.rowquant_mix2_fwd_batch(xs, bits, sym, ups, lows)
+    for want_dx in (True, False):
+        dxs, d_ups, d_lows = F.rowquant_mix2_bwd_batch(gs, xs, bits, sym, ups, lows, want_dx=want_dx)
+        for i, x in enumerate(xs):
+            if x.shape[0] == 0:
+                continue
+            u, l = (ups[i], lows[i]) if lwc else (None, None)
+            o, s, z, _c = F.rowquant_uniform_fwd(x, 4, sym, u, l, 0, bits[i], True)
+            assert same(outs[i].cpu(), o.cpu()) and same(scales[i].cpu(), s.cpu()) and same(rzps[i].cpu(), z.cpu()), i
+            dx, du, dl = F.rowquant_uniform_bwd(gs[i], x, 4, sym, u, l, 0, bits[i], True, want_dx=want_dx)
+            if want_dx:
+                assert same(dxs[i].cpu(), dx.cpu()), i
+            else:
+                assert dxs is None
+            if lwc:
+                assert same(d_ups[i].cpu(), du.cpu()) and same(d_lows[i].cpu(), dl.cpu()), i
+    with pytest.raises(L.MiqError):
+        F.rowquant_mix2_fwd_batch(xs, bits[:1], sym, ups, lows)
