@@ -141,13 +141,14 @@ class _BlockBase(nn.Module):
 
     def _quantize_temp_weights(self):
         """temp_weight <- weight_quantizer(temp_weight) for every linear.  Linears that use the plain uniform quantizer
-        (the exponent quantizer v2, the learnable mixed-bit quantizer) with the same settings and row width share one
-        kernel launch."""
+        (the exponent quantizer v2, the learnable and the fixed mixed-bit quantizers) with the same settings and row width
+        share one kernel launch."""
         from . import functional as F
         from .quantizer import UniformAffineQuantizer
         from .quantizer_exp_v2 import ExpAffineQuantizer as Exp2Quantizer
         from .quantizer_mix import MixAffineQuantizer
-        groups, exp_groups, mix_groups, rest = {}, {}, {}, []
+        from .quantizer_mix_v2 import Mix2AffineQuantizer
+        groups, exp_groups, mix_groups, mix2_groups, rest = {}, {}, {}, {}, []
         for _n, m in self.quant_linears():
             src = m.temp_weight if hasattr(m, "temp_weight") else m.weight
             q = m.weight_quantizer
@@ -166,6 +167,10 @@ class _BlockBase(nn.Module):
                     and src.dtype == torch.float32 and q.n_bits.dtype == torch.float32):
                 key = (src.shape[1], bool(q.symmetric), bool(q.hard_assign), float(q.threshold), bool(q.lwc))
                 mix_groups.setdefault(key, []).append((m, src))
+                continue
+            if (type(q) is Mix2AffineQuantizer and not q.group_size and src.is_cuda and src.dim() == 2
+                    and src.dtype == torch.float32 and (not q.lwc or q.upbound_factor.dtype == src.dtype)):
+                mix2_groups.setdefault((src.shape[1], bool(q.symmetric), bool(q.lwc)), []).append((m, src))
                 continue
             if (type(q) is UniformAffineQuantizer and q.enable and q.n_bits < 16 and q.metric != "fix0to1" and q.dynamic
                     and q.dynamic_method in ("per_token", "per_channel") and not q.group_size and src.is_cuda and src.dim() == 2
@@ -216,6 +221,21 @@ class _BlockBase(nn.Module):
                 if lwc:
                     flat += [q.upbound_factor, q.lowbound_factor]
             res = F.MixRowFQBatch.apply(sym, hard, threshold, lwc, *flat)
+            for j, (m, _src) in enumerate(members):
+                m.temp_weight = res[j]
+        for (_i, sym, lwc), members in mix2_groups.items():
+            if len(members) == 1:
+                rest.append(members[0])
+                continue
+            flat, bits = [], []
+            for m, src in members:
+                q = m.weight_quantizer
+                q.shape = src.shape
+                bits.append(q._row_bits(src))
+                flat.append(src)
+                if lwc:
+                    flat += [q.upbound_factor, q.lowbound_factor]
+            res = F.Mix2RowFQBatch.apply(sym, lwc, bits, *flat)
             for j, (m, _src) in enumerate(members):
                 m.temp_weight = res[j]
         for m, src in rest:

@@ -237,6 +237,41 @@ class UniformRowFQBatch(torch.autograd.Function):
         return tuple(out)
 
 
+class Mix2RowFQBatch(torch.autograd.Function):
+    """apply(symmetric, lwc, row_bits, x_0, [up_0, low_0,] x_1, ...) -> (out_0, out_1, ...): several weight matrices of one
+    width through one forward and one backward launch of the fixed mixed-bit quantizer; row_bits is the list of the
+    matrices' float32 per-row bit-width vectors (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, symmetric, lwc, row_bits, *ts):
+        step = 3 if lwc else 1
+        xs = [t.contiguous() for t in ts[0::step]]
+        ups = list(ts[1::step]) if lwc else None
+        lows = list(ts[2::step]) if lwc else None
+        outs, _scales, _rzps = rowquant_mix2_fwd_batch(xs, row_bits, symmetric, ups, lows)
+        ctx.cfg = (symmetric, lwc, len(xs), list(row_bits))
+        ctx.save_for_backward(*xs, *(ups or []), *(lows or []))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        symmetric, lwc, n, row_bits = ctx.cfg
+        saved = ctx.saved_tensors
+        xs = list(saved[:n])
+        ups = list(saved[n:2 * n]) if lwc else None
+        lows = list(saved[2 * n:3 * n]) if lwc else None
+        gs = [(g if g is not None else torch.zeros_like(x)).contiguous() for g, x in zip(grads, xs)]
+        step = 3 if lwc else 1
+        need_dx = any(ctx.needs_input_grad[3 + i * step] for i in range(n))
+        dxs, d_ups, d_lows = rowquant_mix2_bwd_batch(gs, xs, row_bits, symmetric, ups, lows, want_dx=need_dx)
+        out = [None, None, None]
+        for i in range(n):
+            out.append(dxs[i] if need_dx else None)
+            if lwc:
+                out += [d_ups[i], d_lows[i]]
+        return tuple(out)
+
+
 class UniformRowFQ(torch.autograd.Function):
     """out, scale, rzp = fq(x, up, low); gradients for x, up, low."""
 

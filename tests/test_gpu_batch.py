@@ -282,3 +282,57 @@ def test_mix2_batch_equals_single_matrix_calls(dt, I, rows, lwc, sym):
                 assert same(d_ups[i].cpu(), du.cpu()) and same(d_lows[i].cpu(), dl.cpu()), i
     with pytest.raises(L.MiqError):
         F.rowquant_mix2_fwd_batch(xs, bits[:1], sym, ups, lows)
+
+
+@pytest.mark.parametrize("kind", ["mix", "mix2"])
+def test_block_with_batched_mixed_bit_weights_trains_like_one_launch_per_matrix(kind):
+    """A small OPT-shaped block whose weights go through the learnable (soft and hard phase, with the size loss) or
+    the fixed mixed-bit quantizer: the step that quantizes the weight matrices of one width in one launch each way
+    ends at the same parameters, bit for bit, as the step that launches per matrix."""
+    from miq import blocks
+    from miq.blocks import QuantOPTBlock, quant_args
+    from miq.calibrate import CalibConfig, calibrate_layer
+    H, FF, heads, T = 128, 512, 4, 64
+
+    def one(batched):
+        blocks._BlockBase.batch_weights = batched
+        try:
+            torch.manual_seed(0)
+            g = torch.Generator(device=DEV).manual_seed(7)
+            args = quant_args(wbits=3, abits=16, lwc=True, a_dynamic_method="per_tensor", a_dynamic=False, metric="ema_minmax",
+                              let=False, weight_mix_quant=(kind == "mix"), weight_mix2_quant=(kind == "mix2"))
+            w = lambda o, i: torch.randn(o, i, generator=g, device=DEV, dtype=torch.float16) * 0.05
+            b = lambda o: torch.randn(o, generator=g, device=DEV, dtype=torch.float16) * 0.02
+            one_ = torch.ones(H, device=DEV, dtype=torch.float16)
+            weights = {"q": w(H, H), "k": w(H, H), "v": w(H, H), "o": w(H, H), "fc1": w(FF, H), "fc2": w(H, FF),
+                       "q_b": b(H), "k_b": b(H), "v_b": b(H), "o_b": b(H), "fc1_b": b(FF), "fc2_b": b(H),
+                       "ln1_w": one_, "ln1_b": b(H), "ln2_w": one_.clone(), "ln2_b": b(H)}
+            nbits = None
+            if kind == "mix2":
+                rows = {"q": H, "k": H, "v": H, "o": H, "fc1": FF, "fc2": H}
+                nbits = {n: synth.mix2_bits(r, 310 + i).to(DEV) for i, (n, r) in enumerate(rows.items())}
+            qlayer = QuantOPTBlock(weights, heads, args, nbits=nbits).to(DEV)
+            inps = torch.randn(4, T, H, generator=g, device=DEV)
+            mask = torch.full((T, T), torch.finfo(torch.float32).min, device=DEV).triu(1).view(1, 1, T, T)
+            cfg = CalibConfig(epochs=4 if kind == "mix" else 2, nsamples=4, batch_size=1, let=False, lwc=True, deactive_amp=True,
+                              reorder="", weight_mix_quant=(kind == "mix"), loss_size_coef=0.1)
+            calibrate_layer(qlayer, inps, inps.clone(), mask, cfg, None, None, "model.decoder.layers.0", is_llama=False)
+            return {k: v.detach().clone() for k, v in qlayer.named_parameters()}
+        finally:
+            blocks._BlockBase.batch_weights = True
+
+    name = "rowquant_mix_fwd_batch" if kind == "mix" else "rowquant_mix2_fwd_batch"
+    calls = []
+    real = getattr(F, name)
+    setattr(F, name, lambda xs, *a, **k: (calls.append(len(xs)), real(xs, *a, **k))[1])
+    try:
+        pa = one(True)
+        assert calls and max(calls) >= 4, calls   # q, k, v, out_proj and fc1 share the 128-wide launch
+        n = len(calls)
+        pb = one(False)
+        assert len(calls) == n
+    finally:
+        setattr(F, name, real)
+    assert pa.keys() == pb.keys() and len(pa) > 0
+    for k in pa:
+        assert same(pa[k].cpu(), pb[k].cpu()), k
