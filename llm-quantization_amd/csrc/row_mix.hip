@@ -74,12 +74,16 @@ __device__ __forceinline__ MixCtx mix_ctx(const MixArgs& a, long long row, float
     return c;
 }
 
+// LEVEL: the quotient through level_div (both scales of the row inside its range: a property of the row, tested once
+// there); otherwise the IEEE division.  The level is only rounded and clamped, so the two forms give the same bits.
+template <bool LEVEL>
 __device__ __forceinline__ float grid_level(float xv, const Grid& gr) {
-    const float q = CorrectedDivisor(gr.s, gr.rs).div(xv);
+    const float q = LEVEL ? level_div(xv, gr.s, gr.rs) : xv / gr.s;
     return ((rintf(q) - q) + q) + gr.z;
 }
+template <bool LEVEL>
 __device__ __forceinline__ float grid_fq(float xv, const Grid& gr) {
-    return (clampf(grid_level(xv, gr), 0.f, gr.Q) - gr.z) * gr.s;
+    return (clampf(grid_level<LEVEL>(xv, gr), 0.f, gr.Q) - gr.z) * gr.s;
 }
 
 // the work of one team on one quantization row
@@ -94,17 +98,23 @@ __device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const MixCtx c = mix_ctx(a, row, rmin, rmax);
+    // instantiated for both forms of the quotient: a test inside the element loop would keep the division there
+    auto quantize_row = [&](auto level_tag) {
+        constexpr bool LEVEL = decltype(level_tag)::value;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
-        Pack<float, VEC> o;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+            Pack<float, VEC> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xv = x.v[k].e[e];
-            o.e[e] = c.lo.w * grid_fq(xv, c.lo) + c.hi.w * grid_fq(xv, c.hi);
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = x.v[k].e[e];
+                o.e[e] = c.lo.w * grid_fq<LEVEL>(xv, c.lo) + c.hi.w * grid_fq<LEVEL>(xv, c.hi);
+            }
+            st_pack<float, VEC>(out + base + x.offset(k), o);
         }
-        st_pack<float, VEC>(out + base + x.offset(k), o);
-    }
+    };
+    if (level_div_ok(c.lo.s) && level_div_ok(c.hi.s)) quantize_row(std::true_type{});
+    else quantize_row(std::false_type{});
 }
 
 template <typename T, int VEC, int TEAM, int NV>
