@@ -545,9 +545,11 @@ k_gather(const T* __restrict__ x, const int* __restrict__ idx, T* __restrict__ o
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static inline int pick_chunks(long long R, int col_tiles) {
-    // aim at ~1024 blocks (4 per CU), at least 16 rows per chunk
-    long long want = 1024 / (col_tiles > 0 ? col_tiles : 1);
+constexpr long long kFreshBlocks = 2048;  // block target per slab of the fresh-statistics forward when a launch holds several slabs
+
+static inline int pick_chunks(long long R, int col_tiles, long long target = 1024) {
+    // aim at ~target blocks (1024: 4 per CU), at least 16 rows per chunk
+    long long want = target / (col_tiles > 0 ? col_tiles : 1);
     if (want < 1) want = 1;
     long long maxc = (R + 15) / 16;
     if (want > maxc) want = maxc;
@@ -760,8 +762,16 @@ static int act_fresh_t(int n, const void* const* x, int64_t cluster_size, const 
     }
     const int vec = vec_ok ? N : 1;
     const int tiles = (int)((C / vec + 63) / 64);
-    const int nchunk = pick_chunks(R, tiles);
-    const int rpc = (int)((R + nchunk - 1) / nchunk);
+    // The slot table decouples the two grids from every other kernel's partials, so a launch over several slabs takes
+    // twice the blocks per slab, in row chunks that are whole 16-row batches (measured on the Llama-2-7B sites, policies
+    // side by side on one GPU: three fp32 [2048, 4096] slabs +6 %, two +4 %, three fp16 [2048, 11008] slabs +2 %, fp16
+    // [2048, 4096] unchanged; a single slab loses 2 % and keeps the 1024-block grid).
+    int nchunk = pick_chunks(R, tiles, n >= 2 ? kFreshBlocks : 1024);
+    int rpc = (int)((R + nchunk - 1) / nchunk);
+    if (n >= 2) {
+        rpc = (rpc + 15) / 16 * 16;
+        nchunk = (int)((R + rpc - 1) / rpc);
+    }
     const int64_t nslot = fresh_slots(C, n_clusters, covered);
     const long long ws_stride = fresh_table_words(nslot);
     // every row chunk feeds every slot its column tile touches: spread them over replicas when there are many

@@ -27,10 +27,10 @@ def main():
     fam = json.load(open(prof + f"{tag}_families.json"))
     fam1 = json.load(open(prof + "r01_h_families.json"))
     L = ["# profiles/\n"]
-    L.append(f"MI355X, gfx950, ROCm 7.2, one GPU.  `{tag}_*` is round 2's final build (`r02_a_*`, `r02_b_*`, `r02_c_*`: earlier states of the "
+    L.append(f"MI355X, gfx950, ROCm 7.2, one GPU.  `{tag}_*` is round 2's final build (`r02_a_*`, `r02_b_*`, `r02_c_*`, `r02_f_*`: earlier states of the "
              "round, kept for the history: before the statistics-kernel / cluster-kernel / division work, before the graph-replayed "
-             "calibration step, and before the launch options left the element loops of the fp16 row, exponent, LET and "
-             "attention-score kernels); `r01_*` are round 1's files, described in the second half of this file.  "
+             "calibration step, before the launch options left the element loops of the fp16 row, exponent, LET and "
+             "attention-score kernels, and before the exponent and mixed-bit quantizers took several matrices per launch); `r01_*` are round 1's files, described in the second half of this file.  "
              "`tools/collect_on_gpu.sh <dir>` runs every measurement on the GPU box, `tools/collect_profiles.py <dir> <tag>` installs it "
              "here, `tools/profiles_readme_r02.py <tag>` writes this half of the file.\n")
     L.append("## Round 2\n")
@@ -39,7 +39,7 @@ def main():
     L.append(f"| `{tag}_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-block-calib` |")
     L.append(f"| `{tag}_pmc_fetch_size.csv`, `{tag}_pmc_write_size.csv`, `{tag}_pmc_traffic_per_kernel.json`, `traffic.json` | `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no tracing) on `python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib`; `tools/pmc_summary.py`: HBM bytes per launch = 2·FETCH_SIZE·1024 + WRITE_SIZE·1024; `traffic.json` is what `bench.py` reads for `roofline.traffic` |")
     L.append(f"| `{tag}_sq_rows.json`, `{tag}_sq_bench.json` | `rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES` on `tools/row_pmc.py` (uniform / exponent v1, v2 / mixed-bit row quantizers, fp32 and fp16, forward and backward) and on the eager bench; `tools/row_pmc_summary.py`: per kernel the share of wave cycles issuing any / VALU instructions, parked (`s_waitcnt`, barriers), stalled at issue, VALU instructions per wave |")
-    L.append(f"| `{tag}_families.json` | `tools/bench_families.py`: every operator family on the baseline's named configurations (new: `_x3` = three slabs per call, `C1...batched` = the six OPT-125m matrices through the batched entry points) |")
+    L.append(f"| `{tag}_families.json` | `tools/bench_families.py`: every operator family on the baseline's named configurations (`_x3` = three slabs per call, `...batched` = the matrices of a layer through the batched entry points, one launch per row width) |")
     L.append(f"| `{tag}_bench_c4.json.log` | `python3 bench.py --workload c4` on one GPU: the row-sharded Llama-2-13B mixed-bit workload (BASELINE configs[3]) |")
     L.append(f"| `{tag}_blocks_extra.jsonl`, `{tag}_block7b_kernel_stats.csv`, `{tag}_ab_block.json` | `tools/bench_block.py` for the 13B / 70B shaped blocks, kernel trace of the Llama-2-7B fp16 calibration step, `tools/ab_block.py` |")
     L.append(f"| `{tag}_norm_quant_time.txt` | `tools/dev/norm_quant_time.py`: norm -> activation quantizer as two functions against the norm kernels that publish the statistics themselves |")
