@@ -74,6 +74,25 @@ __device__ __forceinline__ MixCtx mix_ctx(const MixArgs& a, long long row, float
     return c;
 }
 
+// A row whose every level is finite: finite extremes, both scales inside level_div's range, finite zero points, and
+// |x / s| far below the range where the residual of the corrected product could overflow.  There the level needs
+// neither level_div's guard for huge products nor NaN-preserving clamps: a median-of-three is the clamp.
+__device__ __forceinline__ bool mix_plain_row(const MixCtx& c, float rmin, float rmax) {
+    const float a = __builtin_fmaxf(fabsf(rmin), fabsf(rmax));
+    const float bound = a * __builtin_fmaxf(c.lo.rs, c.hi.rs);
+    return (rmin == rmin) && (rmax == rmax) && level_div_ok(c.lo.s) && level_div_ok(c.hi.s) && (bound <= 0x1p60f) &&
+           (fabsf(c.lo.z) <= kClipHi) && (fabsf(c.hi.z) <= kClipHi) && (c.lo.w == c.lo.w) && (c.hi.w == c.hi.w);
+}
+__device__ __forceinline__ float plain_quotient(float xv, const Grid& gr) {
+    const float q0 = xv * gr.rs;
+    return __builtin_fmaf(__builtin_fmaf(-q0, gr.s, xv), gr.rs, q0);
+}
+__device__ __forceinline__ float plain_fq(float xv, const Grid& gr) {
+    const float q = plain_quotient(xv, gr);
+    const float xi = ((rintf(q) - q) + q) + gr.z;
+    return (__builtin_amdgcn_fmed3f(xi, 0.f, gr.Q) - gr.z) * gr.s;
+}
+
 // LEVEL: the quotient through level_div (both scales of the row inside its range: a property of the row, tested once
 // there); otherwise the IEEE division.  The level is only rounded and clamped, so the two forms give the same bits.
 template <bool LEVEL>
@@ -98,9 +117,9 @@ __device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const MixCtx c = mix_ctx(a, row, rmin, rmax);
-    // instantiated for both forms of the quotient: a test inside the element loop would keep the division there
-    auto quantize_row = [&](auto level_tag) {
-        constexpr bool LEVEL = decltype(level_tag)::value;
+    // instantiated per form of the level: a test inside the element loop would keep every form there
+    auto quantize_row = [&](auto form_tag) {
+        constexpr int FORM = decltype(form_tag)::value;  // 2: plain row, 1: level_div, 0: IEEE division
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
@@ -108,13 +127,15 @@ __device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = x.v[k].e[e];
-                o.e[e] = c.lo.w * grid_fq<LEVEL>(xv, c.lo) + c.hi.w * grid_fq<LEVEL>(xv, c.hi);
+                if constexpr (FORM == 2) o.e[e] = c.lo.w * plain_fq(xv, c.lo) + c.hi.w * plain_fq(xv, c.hi);
+                else o.e[e] = c.lo.w * grid_fq<FORM == 1>(xv, c.lo) + c.hi.w * grid_fq<FORM == 1>(xv, c.hi);
             }
             st_pack<float, VEC>(out + base + x.offset(k), o);
         }
     };
-    if (level_div_ok(c.lo.s) && level_div_ok(c.hi.s)) quantize_row(std::true_type{});
-    else quantize_row(std::false_type{});
+    if (mix_plain_row(c, rmin, rmax)) quantize_row(std::integral_constant<int, 2>{});
+    else if (level_div_ok(c.lo.s) && level_div_ok(c.hi.s)) quantize_row(std::integral_constant<int, 1>{});
+    else quantize_row(std::integral_constant<int, 0>{});
 }
 
 template <typename T, int VEC, int TEAM, int NV>
@@ -175,9 +196,12 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
         const float q0 = xv * gr.rs;
         const float q = __builtin_fmaf(__builtin_fmaf(-q0, gr.s, xv), gr.rs, q0);
         const float xi = ((rintf(q) - q) + q) + gr.z;
-        const bool m = (xi >= 0.f) && (xi <= gr.Q);
-        const float xd = clampf(xi, 0.f, gr.Q) - gr.z;
-        dS += gb * (xd - (m ? q : 0.f));
+        // the clamp as a median of three; the level lies inside the grid exactly when the clamp left it alone; a NaN
+        // level (the median drops it) reaches the sum through xi - xi, which is 0 for every other level
+        const float xc = __builtin_amdgcn_fmed3f(xi, 0.f, gr.Q);
+        const bool m = xc == xi;
+        const float xd = xc - gr.z;
+        dS += gb * (xd - (m ? q : xi - xi));
         if (xi > gr.Q) over += gb * gr.s;
         return m ? (gb * gr.s) * gr.rs : 0.f;
     };
