@@ -76,6 +76,45 @@ __device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c, const 
     return r;
 }
 
+// fp32 rows in which every quotient is finite (finite extremes, a scale that is not NaN, |x / s| far below the range
+// where the residual of the corrected product could overflow): the element function without the NaN-preserving forms.
+// Same bits as exp2_elem there: the clamps are medians / minima of finite values, 2^t needs no NaN test, and the sign
+// is copied from q + 0 (sgnf gives 0 for a quotient of either zero, and the level of a zero quotient is 0 already).
+__device__ __forceinline__ bool exp2_plain_row(const Exp2Ctx& c, float rmin, float rmax) {
+    const float bound = __builtin_fmaxf(fabsf(rmin), fabsf(rmax)) / c.s;
+    return (rmin == rmin) && (rmax == rmax) && (bound <= 0x1p60f);  // a NaN scale gives a NaN bound
+}
+__device__ __forceinline__ float exp2_plain_level(float xv, const Exp2Ctx& c, float rs) {
+    const float q0 = xv * rs;
+    const float q = __builtin_fmaf(__builtin_fmaf(-q0, c.s, xv), rs, q0);  // the IEEE quotient for 2^-80 <= |q0|; below it
+    const float a0 = fabsf(q);                                             // the level is 0 whichever way it rounds
+    const float mag = __builtin_amdgcn_fmed3f(a0, 1e-4f, 1e4f);
+    float t = __log2f(div_1p5(mag)) + 0.5f;
+    if (t < -0.5f) t = 0.f;
+    float e = ldexpf(1.0f, (int)rintf(t));
+    if (a0 < 0.5f) e = 0.f;
+    return __builtin_copysignf(__builtin_fminf(e, c.top), q + 0.f);
+}
+
+// the element record of the backward for such a row (fields as exp2_elem fills them)
+__device__ __forceinline__ Exp2Elem exp2_plain_elem(float xv, const Exp2Ctx& c, float rs) {
+    Exp2Elem r;
+    const float q0 = xv * rs;
+    const float q = __builtin_fmaf(__builtin_fmaf(-q0, c.s, xv), rs, q0);
+    const float a0 = fabsf(q);
+    r.sign = __builtin_copysignf((a0 > 0.f) ? 1.f : 0.f, q);
+    r.is_zero = a0 < 0.5f;
+    r.mag = __builtin_amdgcn_fmed3f(a0, 1e-4f, 1e4f);
+    float t = __log2f(div_1p5(r.mag)) + 0.5f;
+    r.below = t < -0.5f;
+    if (r.below) t = 0.f;
+    float e = ldexpf(1.0f, (int)rintf(t));
+    if (r.is_zero) e = 0.f;
+    r.lvl = e;
+    r.signed_lvl = __builtin_copysignf(__builtin_fminf(e, c.top), q + 0.f);
+    return r;
+}
+
 // the work of one team on one quantization row
 template <typename T, int VEC, int TEAM, int NV>
 __device__ __forceinline__ void exp2_fwd_row(const ExpArgs<T>& a, const RowGeom& geo, long long row, int lane, float* lds,
@@ -90,6 +129,20 @@ __device__ __forceinline__ void exp2_fwd_row(const ExpArgs<T>& a, const RowGeom&
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
     const typename FastDivisorOf<T>::type dv(c.s);
     if (lane == 0) scale_out[row] = from_f<T>(c.s);
+    if constexpr (sizeof(T) == 4) {
+        if (exp2_plain_row(c, rmin, rmax)) {  // a property of the row: tested once, not per element
+            const float rs = 1.0f / c.s;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+                Pack<T, VEC> o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_plain_level(to_f<T>(x.v[k].e[e]), c, rs) * c.s);
+                st_pack<T, VEC>(out + base + x.offset(k), o);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (!x.has(k)) continue;
@@ -166,20 +219,31 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     constexpr bool kSide = !kInPlace && NV * VEC <= 32;
     float side[kSide ? NV * VEC : 1];
     float acc[3] = {0.f, 0.f, 0.f};
+    auto row_sums = [&](auto plain_tag) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-            const Exp2Elem el = exp2_elem<T>(xv, c, dv);
-            const float gqq = grad_q(gv, el);
-            if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(gqq);
-            if constexpr (kSide) side[k * VEC + e] = gqq;
-            acc[0] += gv * el.signed_lvl + gqq * (xv * neg_inv_s2);
-            acc[1] += (xv == rmax) ? 1.f : 0.f;
-            acc[2] += (xv == rmin) ? 1.f : 0.f;
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
+                Exp2Elem el;
+                if constexpr (PLAIN) el = exp2_plain_elem(xv, c, inv_s);
+                else el = exp2_elem<T>(xv, c, dv);
+                const float gqq = grad_q(gv, el);
+                if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(gqq);
+                if constexpr (kSide) side[k * VEC + e] = gqq;
+                acc[0] += gv * el.signed_lvl + gqq * (xv * neg_inv_s2);
+                acc[1] += (xv == rmax) ? 1.f : 0.f;
+                acc[2] += (xv == rmin) ? 1.f : 0.f;
+            }
         }
+    };
+    if constexpr (sizeof(T) == 4) {
+        if (exp2_plain_row(c, rmin, rmax)) row_sums(std::true_type{});  // a property of the row, tested once
+        else row_sums(std::false_type{});
+    } else {
+        row_sums(std::false_type{});
     }
     team_sum<TEAM, 3>(acc, lds);
     if (padded) {
