@@ -68,13 +68,17 @@ def main():
     for title, d in ((f"SQ counters, bench kernels (`{tag}_sq_bench.json`; shares of wave cycles)", sq),
                      (f"SQ counters, row quantizers on Llama shapes (`{tag}_sq_rows.json`)", sqr)):
         L.append(f"\n{title}:\n")
-        L.append("| kernel | issuing any | issuing VALU | parked | stalled at issue | VALU insts / wave |\n|---|---|---|---|---|---|")
+        L.append("| kernel | issuing any | issuing VALU | parked | stalled at issue | VALU insts / wave | waves / SIMD (est.) | SIMD VALU busy (est.) |\n|---|---|---|---|---|---|---|---|")
         for k, v in d.items():
-            L.append(f"| `{k}` | {v['active_any_frac']:.2f} | {v['active_valu_frac']:.2f} | {v['wait_any_frac']:.2f} | {v['wait_inst_any_frac']:.2f} | {v['valu_insts_per_wave']:.0f} |")
-    L.append("\nReading: no kernel issues VALU instructions for more than 43 % of its wave cycles, the fp32 ones for 5–28 %; all of them are parked on memory for 40–65 %.  Cutting the uniform forward from 646 to 511 VALU "
-             "instructions per wave (three-operand minima, corrected reciprocal product for the level) moved its bandwidth by 2 %, and replacing the per-element tie counters of the activation backward by running extremes moved it by "
-             "0.3 %: the row and column kernels are bound by latency at their occupancy, not by the vector unit.  The fp16 kernels issue the most arithmetic per byte; packed fp16 instructions would shorten an instruction stream that is "
-             "not the bound.\n")
+            L.append(f"| `{k}` | {v['active_any_frac']:.2f} | {v['active_valu_frac']:.2f} | {v['wait_any_frac']:.2f} | {v['wait_inst_any_frac']:.2f} | {v['valu_insts_per_wave']:.0f} "
+                     f"| {v.get('waves_per_simd_est', float('nan')):.1f} | {v.get('simd_valu_busy_est', float('nan')):.2f} |")
+    L.append("\nReading.  The first four columns are shares of WAVE cycles: a wave of these kernels issues VALU instructions for 5-30 % of its life and is parked on memory for 40-65 %.  "
+             "The last two relate the same counters to the machine (dispatch duration x 1024 SIMDs x 2.4 GHz, `tools/row_pmc_summary.py`): with three to six waves resident per SIMD, the vector units of "
+             "the exponent and mixed-bit kernels and of every fp16 row kernel are busy 70-98 % of the launch, those of the fp32 uniform kernels 50-80 %, those of the activation kernels 25-60 % at under three waves per SIMD.  "
+             "So the exponent, mixed-bit and fp16 row kernels are bound by the vector unit (fewer instructions per element pay there: the per-row choice of a plain element function took the exponent v2 "
+             "forward from 0.65 to 0.69 of peak and its backward from 0.556 to 0.595, the median-of-three clamp the mixed-bit backward from 0.517 to 0.534), the fp32 uniform kernels sit at the copy ceiling with the vector "
+             "unit in second place (646 -> 511 VALU instructions per wave moved the forward by 2 %), and the activation kernels are bound by launch ramp and latency at their occupancy "
+             "(running extremes instead of per-element tie counters: 0.3 %).\n")
     bc = b['block_calib']
     L.append("### Block calibration (`block_calib` of the bench line)\n")
     L.append("| configuration | step | s / optimizer step | s / layer, measured | note |\n|---|---|---|---|---|")
