@@ -114,17 +114,21 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
     // 32 elements per batch keep the kernel under 128 registers (four waves per SIMD) without spills; larger
     // batches were measured: no faster in fp32, slower in fp16
     constexpr int UNR = VEC == 8 ? 2 : 4;  // (fp16 with 4 rows, retried with the one-parameter-set form: 64 bytes of spills, 3 % slower)
-    Pack<T, VEC> a[UNR], b[UNR];
-    auto load_batch = [&](long long r) {
+    // fp16 (two rows per batch: half the bytes in flight of the fp32 form) requests the next batch before it works on
+    // the current one
+    constexpr bool PREFETCH = VEC == 8;
+    Pack<T, VEC> a[UNR], b[UNR], na[PREFETCH ? UNR : 1], nb[PREFETCH ? UNR : 1];
+    auto load_into = [&](Pack<T, VEC>* pa, Pack<T, VEC>* pb, long long r) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const long long rr = r + 4 * u;
             if (rr < r1) {
-                a[u] = ld_pack<T, VEC>(x + rr * C + col0);
-                b[u] = ld_pack<T, VEC>(g + rr * C + col0);
+                pa[u] = ld_pack<T, VEC>(x + rr * C + col0);
+                pb[u] = ld_pack<T, VEC>(g + rr * C + col0);
             }
         }
     };
+    auto load_batch = [&](long long r) { load_into(a, b, r); };
     if (valid) {
         load_batch(r0 + w);
 #pragma unroll
@@ -175,6 +179,9 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
         // (a separate unguarded copy of the batch for the interior of the chunk doubles the code and, with
         // it, the register pressure: measured 2x slower)
         for (long long r = r0 + w; r < r1;) {
+            if constexpr (PREFETCH) {
+                if (r + 4 * UNR < r1) load_into(na, nb, r + 4 * UNR);
+            }
 #pragma unroll
             for (int k = 0; k < NP; ++k) { bmx[k] = -__builtin_inff(); bmn[k] = __builtin_inff(); }
 #pragma unroll
@@ -198,7 +205,12 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
                 }
             }
             r += 4 * UNR;
-            if (r < r1) load_batch(r);
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { a[u] = na[u]; b[u] = nb[u]; }
+            } else {
+                if (r < r1) load_batch(r);
+            }
         }
     };
     if (valid) {
