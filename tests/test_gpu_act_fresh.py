@@ -108,6 +108,29 @@ def test_slabs_of_one_launch_are_independent(dt, n):
         assert same(dxs[i].cpu(), o_dx.cpu()), f"slab {i}: dx"
 
 
+@pytest.mark.parametrize("shape,dt,counts,n", [
+    ((2048, 4096), "f32", [128] * 32, 3), ((2048, 4096), "f32", [128] * 32, 2), ((2048, 4096), "f16", [32] * 128, 3),
+    ((2048, 11008), "f16", [344] * 32, 2), ((2041, 11008), "f32", [344] * 32, 2), ((1000, 5120), "f16", [160] * 32, 3),
+])
+def test_llama_slabs_of_one_launch_equal_their_own_launches(shape, dt, counts, n):
+    """A launch over several slabs cuts the rows into other chunks than a launch over one slab does: outputs, statistics
+    vectors and input gradients stay those of one launch per slab, bit for bit (bench shapes, ragged row counts)."""
+    dtype = DT[dt]
+    R, C = shape
+    layout = F.ClusterLayout.get(counts, C, DEV)
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    xs = [(torch.randn(R, C, device=DEV, generator=gen) * (1 + i)).to(dtype) for i in range(n)]
+    gs = [(torch.randn(R, C, device=DEV, generator=gen) * 1e-3).to(dtype) for _ in range(n)]
+    outs, _codes, vecs = F.act_fresh_quant_fwd(xs, 4, layout)
+    dxs = F.act_fresh_quant_bwd(gs, xs, vecs, 4, layout)
+    for i in range(n):
+        o1, _c1, v1 = F.act_fresh_quant_fwd([xs[i]], 4, layout)
+        d1 = F.act_fresh_quant_bwd([gs[i]], [xs[i]], v1, 4, layout)
+        assert same(outs[i].cpu(), o1[0].cpu()), f"slab {i}: out"
+        assert same(vecs[i].cpu(), v1[0].cpu()), f"slab {i}: statistics"
+        assert same(dxs[i].cpu(), d1[0].cpu()), f"slab {i}: dx"
+
+
 LLAMA = [  # Llama-2 7B / 13B / 70B activation sites of one 2048-token sample
     ((2048, 4096), "f32", [128] * 32), ((2048, 4096), "f16", [32] * 128), ((2048, 11008), "f16", [344] * 32),
     ((2048, 5120), "f32", [160] * 32), ((2048, 13824), "f16", [432] * 32),
