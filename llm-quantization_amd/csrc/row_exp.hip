@@ -102,7 +102,7 @@ __device__ __forceinline__ Exp2Elem exp2_plain_elem(float xv, const Exp2Ctx& c, 
     const float q0 = xv * rs;
     const float q = __builtin_fmaf(__builtin_fmaf(-q0, c.s, xv), rs, q0);
     const float a0 = fabsf(q);
-    r.sign = __builtin_copysignf((a0 > 0.f) ? 1.f : 0.f, q);
+    r.sign = 0.f;  // not used by the plain form of the gradient (see grad_q)
     r.is_zero = a0 < 0.5f;
     r.mag = __builtin_amdgcn_fmed3f(a0, 1e-4f, 1e4f);
     float t = __log2f(div_1p5(r.mag)) + 0.5f;
@@ -202,14 +202,18 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
     const typename BwdDivisorOf<T>::type dv(c.s);
     const float hi_dead = rnd<T>(c.top + 0.0001f), lo_dead = rnd<T>(-c.top + 0.0001f);
-    auto grad_q = [&](float gv, const Exp2Elem& el) {
+    // PLAIN (a row of finite quotients): the sign is +-1 wherever the gradient is not dead, and it enters twice (the
+    // negation of gq and the final factor): the two cancel exactly, so neither is applied
+    auto grad_q = [&](float gv, const Exp2Elem& el, auto plain_tag) {
+        constexpr bool PLAIN_SIGN = decltype(plain_tag)::value;
         float gq = gv * c.s;
-        if (el.sign == -1.f) gq = -gq;
+        if (!PLAIN_SIGN && el.sign == -1.f) gq = -gq;
         // the comparison constants are rounded to the tensor dtype, as the reference's `q_exp.ge(qmax+0.0001)` does
         // (bitwise | and a select: with || and an early return the compiler branches around the product for every element)
         const bool dead = (el.lvl >= hi_dead) | (el.lvl <= lo_dead) | el.is_zero | el.below;
         // gradients are tolerance-checked sums: the hardware reciprocal (1 ulp) instead of an IEEE division (__frcp_rn is one)
-        const float v = (((kLn2 * el.lvl) * gq) * kInvLn2 * __builtin_amdgcn_rcpf(el.mag)) * el.sign;
+        float v = ((kLn2 * el.lvl) * gq) * kInvLn2 * __builtin_amdgcn_rcpf(el.mag);
+        if (!PLAIN_SIGN) v *= el.sign;
         return dead ? 0.f : v;
     };
     const float inv_s = 1.0f / c.s, neg_inv_s2 = -1.0f / (c.s * c.s);
@@ -230,7 +234,7 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
                 Exp2Elem el;
                 if constexpr (PLAIN) el = exp2_plain_elem(xv, c, inv_s);
                 else el = exp2_elem<T>(xv, c, dv);
-                const float gqq = grad_q(gv, el);
+                const float gqq = grad_q(gv, el, plain_tag);
                 if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(gqq);
                 if constexpr (kSide) side[k * VEC + e] = gqq;
                 acc[0] += gv * el.signed_lvl + gqq * (xv * neg_inv_s2);
@@ -268,7 +272,7 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
                 float gqq;
                 if constexpr (kInPlace) gqq = gv;  // overwritten above
                 else if constexpr (kSide) gqq = side[k * VEC + e];
-                else gqq = grad_q(gv, exp2_elem<T>(xv, c, dv));
+                else gqq = grad_q(gv, exp2_elem<T>(xv, c, dv), std::false_type{});
                 float d = gqq * inv_s;
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
