@@ -387,6 +387,28 @@ __device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, b
     rmax = mm[1];
 }
 
+// The same, also telling the lane whether one of ITS elements can equal a row extreme (its own extremes reach the
+// row's): kernels that count and correct the elements at the extremes can skip both for every other lane.
+template <typename T, int VEC, int TEAM, int NV>
+__device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, bool padded, float* lds,
+                                           float& rmin, float& rmax, bool& lane_at_extreme) {
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    bool any_nan = false;
+    x.for_each([&](int, int, float a) {
+        mn = __builtin_fminf(mn, a);
+        mx = __builtin_fmaxf(mx, a);
+        any_nan = any_nan || (a != a);
+    });
+    const float lmn = mn, lmx = mx;  // of the lane's own elements (padding is not an element)
+    if (padded) { mn = __builtin_fminf(mn, 0.f); mx = __builtin_fmaxf(mx, 0.f); }
+    if (any_nan) mn = mx = __builtin_nanf("");
+    float mm[2] = {mn, mx};
+    team_reduce<TEAM, 2>(mm, OpMinMax(), lds);
+    rmin = mm[0];
+    rmax = mm[1];
+    lane_at_extreme = (lmn == rmin) || (lmx == rmax);  // never true in a NaN row, where no element equals the extremes
+}
+
 // ---------------------------------------------------------------------------------------------
 // Learnable weight clipping shared by all row-wise quantizers:
 //   xmax = sigmoid(up) * rowmax, xmin = sigmoid(low) * rowmin   (reference quantizer.py:259-261)

@@ -198,7 +198,12 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     g.load(gout + base, len, lane);
     const bool padded = len < geo.g;
     float rmin, rmax;
-    row_minmax(x, padded, lds, rmin, rmax);
+    // fp32: the elements at the row extremes (rarely in more than two lanes of a row) are counted and corrected only by
+    // the lanes that hold them
+    constexpr bool kLaneTies = sizeof(T) == 4;
+    bool at_extreme = true;
+    if constexpr (kLaneTies) row_minmax(x, padded, lds, rmin, rmax, at_extreme);
+    else row_minmax(x, padded, lds, rmin, rmax);
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
     const typename BwdDivisorOf<T>::type dv(c.s);
     const float hi_dead = rnd<T>(c.top + 0.0001f), lo_dead = rnd<T>(-c.top + 0.0001f);
@@ -238,8 +243,10 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
                 if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(gqq);
                 if constexpr (kSide) side[k * VEC + e] = gqq;
                 acc[0] += gv * el.signed_lvl + gqq * (xv * neg_inv_s2);
-                acc[1] += (xv == rmax) ? 1.f : 0.f;
-                acc[2] += (xv == rmin) ? 1.f : 0.f;
+                if constexpr (!kLaneTies) {
+                    acc[1] += (xv == rmax) ? 1.f : 0.f;
+                    acc[2] += (xv == rmin) ? 1.f : 0.f;
+                }
             }
         }
     };
@@ -248,6 +255,14 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
         else row_sums(std::false_type{});
     } else {
         row_sums(std::false_type{});
+    }
+    if constexpr (kLaneTies) {
+        if (at_extreme) {
+            x.for_each([&](int, int, float xv) {
+                acc[1] += (xv == rmax) ? 1.f : 0.f;
+                acc[2] += (xv == rmin) ? 1.f : 0.f;
+            });
+        }
     }
     team_sum<TEAM, 3>(acc, lds);
     if (padded) {
@@ -259,6 +274,39 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     float d_xmax, d_xmin;
     route_absmax(live ? acc[0] / c.qdiv : 0.f, c.clip, d_xmax, d_xmin);
     if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+    if constexpr (kLaneTies) {  // (fp32: g holds the per-element gradient w.r.t. x / s)
+        if (dx) {
+            if (at_extreme) {  // one lane-level branch around two compares per element
+                const float share_max = (d_xmax * c.clip.su) / acc[1];
+                const float share_min = (d_xmin * c.clip.sl) / acc[2];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float xv = to_f<T>(x.v[k].e[e]);
+                        float d = to_f<T>(g.v[k].e[e]) * inv_s;
+                        if (xv == rmax) d += share_max;
+                        if (xv == rmin) d += share_min;
+                        g.v[k].e[e] = from_f<T>(d);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g.v[k].e[e] = from_f<T>(to_f<T>(g.v[k].e[e]) * inv_s);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+                st_pack<T, VEC>(dx + base + x.offset(k), g.v[k]);
+            }
+        }
+        return;
+    }
     if (dx) {
         const float share_max = (d_xmax * c.clip.su) / acc[1];
         const float share_min = (d_xmin * c.clip.sl) / acc[2];
