@@ -185,7 +185,8 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
     g.load(gout + base, len, lane);
     const bool padded = len < geo.g;
     float rmin, rmax;
-    row_minmax(x, padded, lds, rmin, rmax);
+    bool at_extreme;  // one of this lane's elements equals a row extreme (rarely true in more than two lanes of a row)
+    row_minmax(x, padded, lds, rmin, rmax, at_extreme);
     const MixCtx c = mix_ctx(a, row, rmin, rmax);
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dS_lo, dS_hi, over_lo, over_hi, #max, #min
     // returns the straight-through part of dx through this grid (what autograd forms as ((g*w)*s)/s)
@@ -215,9 +216,13 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
             d += terms(xv, gv, c.lo, acc[0], acc[2]);
             d += terms(xv, gv, c.hi, acc[1], acc[3]);
             g.v[k].e[e] = d;  // g is not read again: its registers carry the direct gradient to the dx pass
+        }
+    }
+    if (at_extreme) {  // the elements at the extremes are counted (and corrected, below) only by the lanes that hold them
+        x.for_each([&](int, int, float xv) {
             acc[4] += (xv == rmax) ? 1.f : 0.f;
             acc[5] += (xv == rmin) ? 1.f : 0.f;
-        }
+        });
     }
     team_sum<TEAM, 6>(acc, lds);
     if (padded) {
@@ -247,21 +252,26 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
         if (a.up) write_lwc_grads<float>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
     }
     if (dx) {
-        const float share_max = (d_xmax * c.clip.su) / acc[4];
-        const float share_min = (d_xmin * c.clip.sl) / acc[5];
+        if (at_extreme) {
+            const float share_max = (d_xmax * c.clip.su) / acc[4];
+            const float share_min = (d_xmin * c.clip.sl) / acc[5];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xv = x.v[k].e[e];
+                    float d = g.v[k].e[e];
+                    if (xv == rmax) d += share_max;
+                    if (xv == rmin) d += share_min;
+                    g.v[k].e[e] = d;
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
-            Pack<float, VEC> o;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float xv = x.v[k].e[e];
-                float d = g.v[k].e[e];
-                if (xv == rmax) d += share_max;
-                if (xv == rmin) d += share_min;
-                o.e[e] = d;
-            }
-            st_pack<float, VEC>(dx + base + x.offset(k), o);
+            st_pack<float, VEC>(dx + base + x.offset(k), g.v[k]);
         }
     }
 }
