@@ -76,7 +76,7 @@ def main():
              "The last two relate the same counters to the machine (dispatch duration x 1024 SIMDs x 2.4 GHz, `tools/row_pmc_summary.py`): with three to six waves resident per SIMD, the vector units of "
              "the exponent and mixed-bit kernels and of every fp16 row kernel are busy 70-98 % of the launch, those of the fp32 uniform kernels 50-80 %, those of the activation kernels 25-60 % at under three waves per SIMD.  "
              "So the exponent, mixed-bit and fp16 row kernels are bound by the vector unit (fewer instructions per element pay there: the per-row choice of a plain element function took the exponent v2 "
-             "forward from 0.65 to 0.69 of peak and its backward from 0.556 to 0.595, the median-of-three clamp the mixed-bit backward from 0.517 to 0.534), the fp32 uniform kernels sit at the copy ceiling with the vector "
+             "forward from 0.65 to 0.70 of peak and its backward from 0.556 to 0.62, the same with lane-level tie handling the mixed-bit backward from 0.517 to 0.553), the fp32 uniform kernels sit at the copy ceiling with the vector "
              "unit in second place (646 -> 511 VALU instructions per wave moved the forward by 2 %), and the activation kernels are bound by launch ramp and latency at their occupancy "
              "(running extremes instead of per-element tie counters: 0.3 %).\n")
     bc = b['block_calib']
