@@ -410,6 +410,25 @@ __device__ __forceinline__ float exp1_out(const Exp1Elem& el, const Exp1Ctx& c) 
     return o;
 }
 
+// fp32 rows in which every quotient is finite (see exp2_plain_row): the v1 element without the NaN-preserving forms.
+// Same bits as exp1_elem + exp1_out there; the sign is copied from v, and a zero v gives the zero sgnf gives.
+__device__ __forceinline__ bool exp1_plain_row(const Exp1Ctx& c, float rmin, float rmax) {
+    const float bound = 2.f * __builtin_fmaxf(fabsf(rmin), fabsf(rmax)) / c.s;
+    return (rmin == rmin) && (rmax == rmax) && (bound <= 0x1p60f) && (fabsf(c.mid) <= 0x1p100f);
+}
+__device__ __forceinline__ float exp1_plain_out(float xv, const Exp1Ctx& c, float rs) {
+    const float v = c.has_mid ? xv - c.mid : xv;
+    const float q0 = v * rs;
+    const float u = __builtin_fmaf(__builtin_fmaf(-q0, c.s, v), rs, q0);  // below 2^-80 the magnitude clamps to 1e-5 either way
+    const float mag = __builtin_amdgcn_fmed3f(fabsf(u), kClipLo, kClipHi);
+    const float l = __log2f(mag);
+    const float lround = (rintf(l) - l) + l;
+    const float p = ldexpf(1.0f, (int)__builtin_amdgcn_fmed3f(lround, c.e_lo, 0.f));
+    const float ps = (v != 0.f) ? __builtin_copysignf(p, v) : 0.f;
+    const float o = ps * c.s;
+    return c.has_mid ? o + c.mid : o;
+}
+
 template <typename T, int VEC, int TEAM, int NV>
 __global__ void __launch_bounds__(block_of<TEAM>())
 k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out, T* __restrict__ mid_out) {
@@ -430,6 +449,20 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     if (lane == 0) {
         scale_out[row] = from_f<T>(c.s);
         if (mid_out) mid_out[row] = from_f<T>(c.mid);
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (exp1_plain_row(c, rmin, rmax)) {  // a property of the row: tested once, not per element
+            const float rs = 1.0f / c.s;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+                Pack<T, VEC> o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_plain_out(to_f<T>(x.v[k].e[e]), c, rs));
+                st_pack<T, VEC>(out + base + x.offset(k), o);
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -462,7 +495,11 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     g.load(gout + base, len, lane);
     const bool padded = len < geo.g;
     float rmin, rmax;
-    row_minmax(x, padded, lds, rmin, rmax);
+    // fp32: the elements at the row extremes are counted and corrected only by the lanes that hold them (k_exp2_bwd)
+    constexpr bool kLaneTies = sizeof(T) == 4;
+    bool at_extreme = true;
+    if constexpr (kLaneTies) row_minmax(x, padded, lds, rmin, rmax, at_extreme);
+    else row_minmax(x, padded, lds, rmin, rmax);
     const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
     const typename BwdDivisorOf<T>::type dv(c.s);
     const float alo = rnd<T>(kClipLo);
@@ -489,8 +526,18 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
             if constexpr (kSide) side[k * VEC + e] = du;
             acc[0] += gv * (el.p * el.sign) + du * (el.v * neg_inv_s2);
             acc[1] += gv - du * inv_s;
-            acc[2] += (xv == rmax) ? 1.f : 0.f;
-            acc[3] += (xv == rmin) ? 1.f : 0.f;
+            if constexpr (!kLaneTies) {
+                acc[2] += (xv == rmax) ? 1.f : 0.f;
+                acc[3] += (xv == rmin) ? 1.f : 0.f;
+            }
+        }
+    }
+    if constexpr (kLaneTies) {
+        if (at_extreme) {
+            x.for_each([&](int, int, float xv) {
+                acc[2] += (xv == rmax) ? 1.f : 0.f;
+                acc[3] += (xv == rmin) ? 1.f : 0.f;
+            });
         }
     }
     team_sum<TEAM, 4>(acc, lds);
@@ -509,6 +556,39 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
         d_xmin = -d_range + acc[1] / 2.f;
     }
     if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+    if constexpr (kLaneTies) {  // (fp32: g holds the per-element gradient w.r.t. the quotient)
+        if (dx) {
+            if (at_extreme) {
+                const float share_max = (d_xmax * c.clip.su) / acc[2];
+                const float share_min = (d_xmin * c.clip.sl) / acc[3];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float xv = to_f<T>(x.v[k].e[e]);
+                        float d = to_f<T>(g.v[k].e[e]) * inv_s;
+                        if (xv == rmax) d += share_max;
+                        if (xv == rmin) d += share_min;
+                        g.v[k].e[e] = from_f<T>(d);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g.v[k].e[e] = from_f<T>(to_f<T>(g.v[k].e[e]) * inv_s);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (!x.has(k)) continue;
+                st_pack<T, VEC>(dx + base + x.offset(k), g.v[k]);
+            }
+        }
+        return;
+    }
     if (dx) {
         const float share_max = (d_xmax * c.clip.su) / acc[2];
         const float share_min = (d_xmin * c.clip.sl) / acc[3];
