@@ -23,8 +23,14 @@ value = algorithmic bytes of the step (read-once/write-once accounting: fwd 2ns,
 quantize 3ns, gather 2ns) summed over all ranks / wall time of the slowest rank.  Inputs are resident
 in HBM before the timed region.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W]    (N>1: launched by torch.distributed.run)
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+With N > 1 and no WORLD_SIZE in the environment the script starts its own ranks (one per GPU) through
+torch.distributed.run as a child process and relays rank 0's line; under torch.distributed.run it is a rank.
 Prints ONE JSON line on rank 0.
+
+Beside the timed step the line carries, measured outside the timed region: `families_c3_c4` (the exponent and mixed-bit
+quantizer families on the Llama-2-7B / Llama-2-13B weight shapes: the other two of the five operator families),
+`block_calib` (seconds per layer of the calibration loop) and `cpu_baseline`.
 
 --workload c4 runs the row-sharded weight workload instead: the seven matrices of one Llama-2-13B layer (fp32) through the
 learnable mixed-bit quantizer in its soft and hard phases (forward + backward including d n_bits) and the fixed mixed-bit
@@ -92,6 +98,19 @@ class Segments:
         return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.ev.items()}
 
 
+def _capture_all(fams, side):
+    """One HIP graph per family, captured on the stream the warm-up ran on (per-stream state of the library -- the
+    statistics table of the activation kernels -- is warm there, so nothing is allocated inside a capture)."""
+    pool = torch.cuda.graph_pool_handle()
+    out = []
+    for name, fn in fams:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, stream=side):
+            fn()
+        out.append((name, g.replay))
+    return out
+
+
 class Workload:
     def __init__(self, dev, seed):
         self.dev = dev
@@ -99,7 +118,7 @@ class Workload:
         for i, (_n, o, c) in enumerate(WEIGHTS):
             self.w.append(synth.weight(o, c, seed + i).to(dev))
             self.gw.append((synth.grad_like(self.w[-1].cpu(), seed + 50 + i) * 1e-3).to(dev))
-            u, l = synth.lwc_factors(o, seed + 100 + i)
+            u, l = synth.lwc_clips(o, seed + 100 + i)
             self.up.append(u.to(dev))
             self.low.append(l.to(dev))
         self.x, self.gx, self.layout = [], [], []
@@ -188,14 +207,7 @@ class Workload:
                     fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        pool = torch.cuda.graph_pool_handle()
-        out = []
-        for name, fn in fams:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                fn()
-            out.append((name, g.replay))
-        return out
+        return _capture_all(fams, side)
 
     def step(self, fams, seg: Segments, timed: bool, world: int):
         for name, fn in fams:
@@ -236,7 +248,7 @@ class C4Workload:
             del full
             rows = self.w[-1].shape[0]
             self.g.append(torch.randn(rows, c, device=dev, generator=gen) * 1e-3)
-            u, l = synth.lwc_factors(o, 1400 + i)
+            u, l = synth.lwc_clips(o, 1400 + i)
             self.up.append(u[sl].contiguous().to(dev))
             self.low.append(l[sl].contiguous().to(dev))
             self.bits.append(synth.mix_bits(o, 3.0, 1500 + i)[sl].contiguous().to(dev))
@@ -303,14 +315,7 @@ class C4Workload:
                     fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        pool = torch.cuda.graph_pool_handle()
-        out = []
-        for name, fn in fams:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                fn()
-            out.append((name, g.replay))
-        return out
+        return _capture_all(fams, side)
 
     def all_gather(self):
         from miq.dist import gather_row_shards
@@ -403,7 +408,7 @@ def cpu_baseline(threads: int):
 
     torch.set_num_threads(threads)
     w = synth.weight(H, H, 2)
-    up, low = synth.lwc_factors(H, 3)
+    up, low = synth.lwc_factors(H, 3)  # raw factors: the oracle applies the sigmoid itself
     gw = synth.grad_like(w, 4)
     a = synth.activation((1, T, H), 5)
     ga = synth.grad_like(a, 6)

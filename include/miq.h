@@ -36,14 +36,17 @@ extern "C" {
 
 /* flags of miq_rowquant_uniform_* */
 #define MIQ_CLAMP_ASYM_SCALE 1 /* clamp the asymmetric scale to [1e-5, 1e4] (quantizer_mix_v2.py:140) */
-#define MIQ_LWC_PREACTIVATED 2 /* up/low already hold sigmoid(factor) in (0,1); d_up/d_low are then the
-                                  gradients w.r.t. those values.  Results are a pure function of IEEE
-                                  add/mul/div/round and therefore bit-reproducible on any device; without
-                                  the flag the kernel evaluates 1/(1+expf(-f)) itself, whose last bit
-                                  depends on the math library. */
+/* Learnable weight clipping, every row-wise entry point: `up` / `low` hold the ACTIVATED clip factors
+ * sigmoid(upbound_factor), sigmoid(lowbound_factor) in (0, 1) -- the tensors the reference forms at
+ * quantize/quantizer.py:259-261 before it multiplies them with the row extremes -- and `d_up` / `d_low` receive the
+ * gradients with respect to those activated values (the caller chains sigmoid' = s*(1-s), as autograd does through
+ * torch.sigmoid).  Every result of the library is then a pure function of IEEE add / mul / div / round and bit-identical
+ * to the reference's op sequence; a sigmoid evaluated inside the kernels would depend on the device math library's exp
+ * in its last bit, and one bit of a clip factor moves the scale of a whole row.  (Interface versions below 300 took the
+ * raw factors and a flag bit 1 for this form; the bit is ignored now.) */
 
 /* major*10000 + minor*100 + patch of this interface; it grows when an entry point is added or a signature changes
- * (200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
+ * (300: up / low are the activated clip factors in every row-wise entry point; 200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
  * miq_act_quant_from_table, miq_gather_layernorm_bwd, miq_act_calib_quant_fwd_static) */
 int miq_version(void);
 const char* miq_last_error(void);
@@ -54,7 +57,7 @@ const char* miq_last_error(void);
  * (quantize/quantizer.py:248-273 and :99-121); with `row_bits` != NULL it is
  * Mix2AffineQuantizer.forward (quantize/quantizer_mix_v2.py:116-146).
  *   x         [O, I]            input
- *   up, low   [rows] or NULL    raw LWC factors (sigmoid is applied inside), both or neither
+ *   up, low   [rows] or NULL    activated LWC factors sigmoid(upbound_factor), sigmoid(lowbound_factor); both or neither
  *   row_bits  [rows] f32|NULL   per-row integer bit-widths; overrides n_bits
  *   out       [O, I]            dequantized result
  *   scale_out, rzp_out [rows]   scale and rounded zero point that were used
@@ -67,9 +70,9 @@ int miq_rowquant_uniform_fwd(const void* x, const void* up, const void* low, con
 
 /*
  * Backward of the above: what autograd derives from round_ste (quantize/quantizer.py:13-17)
- * through amin/amax, sigmoid and the scale.  Statistics are recomputed from x.
+ * through amin/amax, the clip product and the scale.  Statistics are recomputed from x.
  *   grad_out [O, I]; dx [O, I] or NULL (skip the input gradient); d_up, d_low [rows] (required
- *   iff up/low are given).
+ *   iff up/low are given): gradients of the activated factors.
  */
 int miq_rowquant_uniform_bwd(const void* grad_out, const void* x, const void* up, const void* low,
                              const float* row_bits, void* dx, void* d_up, void* d_low,
@@ -293,7 +296,7 @@ int miq_gather_layernorm_bwd(const void* grad_out, const void* x, const int* idx
  * Exponential/log weight quantizer v2 (levels 0, +-1, +-2, ..., +-2^(2^(n-1)-2)), n_bits in [2, 4].
  * Replaces ExpAffineQuantizer.per_channel_dynamic_calibration + FakeQuant.forward / backward
  * (quantize/quantizer_exp_v2.py:186-204, :21-62, :65-105 — the backward is the reference's own
- * hand-written rule dx = g * level/|x/s|, not the true derivative).  flags: MIQ_LWC_PREACTIVATED.
+ * hand-written rule dx = g * level/|x/s|, not the true derivative).  flags: reserved, pass 0.
  */
 int miq_rowquant_exp2_fwd(const void* x, const void* up, const void* low, void* out, void* scale_out,
                           int64_t O, int64_t I, int64_t group, int n_bits, int flags, int dtype, void* stream);
@@ -364,8 +367,8 @@ int miq_reorder_index(const float* xmax, const float* xmin, int64_t C, int n_hea
  * (w * cs[None,:]) * rs[:,None] (rs_div = 0), the smoothed weight that smooth_ln_fcs_temporary /
  * smooth_fc_fc_temporary / smooth_q_k_temporary (models/transformation.py:24-69) materialise
  * before UniformAffineQuantizer.forward (quantize/quantizer.py:124-142); same IEEE operations in the
- * same order, so `out`, `scale_out`, `rzp_out` are bit-identical to that chain (for pre-activated
- * clipping factors; see MIQ_LWC_PREACTIVATED).  cs, rs, shift, up/low may each be NULL.
+ * same order, so `out`, `scale_out`, `rzp_out` are bit-identical to that chain (up / low: activated
+ * clip factors, as everywhere).  cs, rs, shift, up/low may each be NULL.
  * out_dtype MIQ_F16 stores the fp32 result rounded to fp16 (what the autocast of the consuming
  * linear would produce from the fp32 tensor).
  * With `shift`, wshift_out[o] = sum_i w[o,i] * shift[i] (the `fc.weight @ shifts` term of the

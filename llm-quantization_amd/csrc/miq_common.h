@@ -89,11 +89,6 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {
 }
 __device__ __forceinline__ float sgnf(float v) { return (float)((0.f < v) - (v < 0.f)); }
 
-// sigmoid exactly as 1/(1+exp(-x)) in fp32 (ATen's formula), rounded to T
-template <typename T> __device__ __forceinline__ float sigmoid_t(float x) {
-    return rnd<T>(1.0f / (1.0f + expf(-x)));
-}
-
 // ---------------------------------------------------------------------------------------------
 // x / s rounded to T, for a divisor that is reused many times.
 //   float: plain IEEE division (the kernels that use it are bound by memory, the ~12 VALU ops are hidden).
@@ -412,14 +407,17 @@ __device__ __forceinline__ void row_minmax(const RowTile<T, VEC, TEAM, NV>& x, b
 // ---------------------------------------------------------------------------------------------
 // Learnable weight clipping shared by all row-wise quantizers:
 //   xmax = sigmoid(up) * rowmax, xmin = sigmoid(low) * rowmin   (reference quantizer.py:259-261)
+// The library receives the ACTIVATED factors su = sigmoid(up), sl = sigmoid(low): the caller evaluates the sigmoid
+// with the same routine the reference uses (a device math library's exp differs from it in the last bit, and
+// one bit of the clip factor moves the scale of the whole row), and chains sigmoid' onto the returned gradients.
 // ---------------------------------------------------------------------------------------------
 struct ClipCtx {
-    float su, sl;      // sigmoid(up), sigmoid(low); 1 when LWC is off
+    float su, sl;      // activated clip factors; 1 when LWC is off
     float xmax, xmin;  // clipped bounds
 };
 
 template <typename T>
-__device__ __forceinline__ ClipCtx lwc_clip(const T* up, const T* low, int preact, long long row, float rmin, float rmax) {
+__device__ __forceinline__ ClipCtx lwc_clip(const T* up, const T* low, long long row, float rmin, float rmax) {
     ClipCtx c;
     c.su = 1.f;
     c.sl = 1.f;
@@ -428,10 +426,6 @@ __device__ __forceinline__ ClipCtx lwc_clip(const T* up, const T* low, int preac
     if (up) {
         c.su = to_f<T>(up[row]);
         c.sl = to_f<T>(low[row]);
-        if (!preact) {
-            c.su = sigmoid_t<T>(c.su);
-            c.sl = sigmoid_t<T>(c.sl);
-        }
         c.xmax = rnd<T>(c.su * rmax);
         c.xmin = rnd<T>(c.sl * rmin);
     }
@@ -447,14 +441,12 @@ __device__ __forceinline__ void route_absmax(float d_amax, const ClipCtx& c, flo
     d_xmin = db * sgnf(c.xmin);
 }
 
-// d_up / d_low from the gradients of the clipped bounds (chain through the multiply and the sigmoid)
+// gradients of the activated clip factors from the gradients of the clipped bounds (chain through the multiply)
 template <typename T>
-__device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, int preact, long long row, const ClipCtx& c,
-                                                float rmin, float rmax, float d_xmax, float d_xmin) {
-    const float ju = preact ? 1.f : c.su * (1.f - c.su);
-    const float jl = preact ? 1.f : c.sl * (1.f - c.sl);
-    d_up[row] = from_f<T>(d_xmax * rmax * ju);
-    d_low[row] = from_f<T>(d_xmin * rmin * jl);
+__device__ __forceinline__ void write_lwc_grads(T* d_up, T* d_low, long long row, float rmin, float rmax, float d_xmax,
+                                                float d_xmin) {
+    d_up[row] = from_f<T>(d_xmax * rmax);
+    d_low[row] = from_f<T>(d_xmin * rmin);
 }
 
 // Several matrices of one row width in ONE launch (the weight matrices of a block are quantized back to

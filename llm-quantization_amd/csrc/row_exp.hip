@@ -24,7 +24,6 @@ struct ExpArgs {
     const T* low;
     int n_bits;
     int symmetric;  // v1 only
-    int preact;
 };
 
 // v / 1.5f as the IEEE quotient through the corrected reciprocal product (see CorrectedDivisor; v lies in
@@ -44,7 +43,7 @@ struct Exp2Ctx {
 template <typename T>
 __device__ __forceinline__ Exp2Ctx exp2_ctx(const ExpArgs<T>& a, long long row, float rmin, float rmax) {
     Exp2Ctx c;
-    c.clip = lwc_clip<T>(a.up, a.low, a.preact, row, rmin, rmax);
+    c.clip = lwc_clip<T>(a.up, a.low, row, rmin, rmax);
     c.top = (float)(1 << ((1 << (a.n_bits - 1)) - 2));
     c.qdiv = 2.f * c.top;
     const float amax = nmax(fabsf(c.clip.xmax), fabsf(c.clip.xmin));
@@ -273,7 +272,7 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     const bool live = c.s_raw >= rnd<T>(kClipLo) && c.s_raw <= kClipHi;
     float d_xmax, d_xmin;
     route_absmax(live ? acc[0] / c.qdiv : 0.f, c.clip, d_xmax, d_xmin);
-    if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+    if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, row, rmin, rmax, d_xmax, d_xmin);
     if constexpr (kLaneTies) {  // (fp32: g holds the per-element gradient w.r.t. x / s)
         if (dx) {
             if (at_extreme) {  // one lane-level branch around two compares per element
@@ -369,7 +368,7 @@ struct Exp1Ctx {
 template <typename T>
 __device__ __forceinline__ Exp1Ctx exp1_ctx(const ExpArgs<T>& a, long long row, float rmin, float rmax) {
     Exp1Ctx c;
-    c.clip = lwc_clip<T>(a.up, a.low, a.preact, row, rmin, rmax);
+    c.clip = lwc_clip<T>(a.up, a.low, row, rmin, rmax);
     c.e_lo = -(float)((1 << (a.n_bits - 1)) - 1);
     const float lo = rnd<T>(kClipLo);
     if (a.symmetric) {
@@ -555,7 +554,7 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
         d_xmax = d_range + acc[1] / 2.f;
         d_xmin = -d_range + acc[1] / 2.f;
     }
-    if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+    if (a.up && lane == 0) write_lwc_grads<T>(d_up, d_low, row, rmin, rmax, d_xmax, d_xmin);
     if constexpr (kLaneTies) {  // (fp32: g holds the per-element gradient w.r.t. the quotient)
         if (dx) {
             if (at_extreme) {
@@ -637,7 +636,6 @@ static int launch_exp(int which, bool backward, const void* gout, const void* x,
     a.low = (const T*)low;
     a.n_bits = n_bits;
     a.symmetric = symmetric;
-    a.preact = (flags >> 1) & 1;
     if (which == 2) {
         if (!backward) MIQ_ROW_LAUNCH(k_exp2_fwd, T, vec_ok, geo, stream, a, geo, (T*)out_or_dx, (T*)a1);
         else MIQ_ROW_LAUNCH_SIZED(k_exp2_bwd, T, vec_ok, geo, stream, a, geo, (const T*)gout, (T*)out_or_dx, (T*)a1, (T*)a2);
@@ -695,7 +693,6 @@ static int launch_exp2_batch(bool backward, int n, const void* const* gout, cons
     ExpArgs<T> a{};
     a.n_bits = n_bits;
     a.symmetric = 1;
-    a.preact = (flags >> 1) & 1;
     const int npack = vec_ok ? geo.g / N : geo.g;
     MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
 #define LAUNCH_ONE(KERN, VECN, TEAM, NV)                                                                       \

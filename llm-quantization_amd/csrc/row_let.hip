@@ -30,7 +30,6 @@ struct LetArgs {
     const float* shift;  // [I] or nullptr: wshift[o] = sum_i w[o,i] * shift[i]
     const float* up;     // [O] LWC factors or nullptr
     const float* low;
-    int preact;
     int n_bits;
     int symmetric;
     long long O;
@@ -47,7 +46,7 @@ __device__ __forceinline__ LetCtx let_ctx(const LetArgs& a, long long row, float
     LetCtx c;
     const float n = (float)a.n_bits;
     c.qmax = exp2f(n) - 1.0f;
-    const ClipCtx cl = lwc_clip<float>(a.up, a.low, a.preact, row, rmin, rmax);
+    const ClipCtx cl = lwc_clip<float>(a.up, a.low, row, rmin, rmax);
     c.su = cl.su;
     c.sl = cl.sl;
     c.xmax = cl.xmax;
@@ -245,10 +244,8 @@ k_let_bwd_rows(LetArgs a, const TG* __restrict__ gout, float* __restrict__ d_up,
     }
     if (lane != 0) return;
     if (a.up) {
-        const float ju = a.preact ? 1.f : c.su * (1.f - c.su);
-        const float jl = a.preact ? 1.f : c.sl * (1.f - c.sl);
-        d_up[row] = d_xmax * rmax * ju;
-        d_low[row] = d_xmin * rmin * jl;
+        d_up[row] = d_xmax * rmax;   // w.r.t. the activated factors
+        d_low[row] = d_xmin * rmin;
     }
     const float tot_max = d_xmax * c.su, tot_min = d_xmin * c.sl;  // gradient mass routed to the row max / min
     if (has_r && d_rs) {
@@ -467,7 +464,7 @@ extern "C" int miq_let_rowquant_fwd(const float* w, const float* cs, const float
                                     float* wshift_out, int64_t O, int64_t I, int n_bits, int symmetric, int flags,
                                     int out_dtype, void* stream) {
     if (O == 0 || I == 0) return 0;
-    LetArgs a{w, cs, rs, rs_div, shift, up, low, (flags >> 1) & 1, n_bits, symmetric, O, (int)I};
+    LetArgs a{w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, O, (int)I};
     MIQ_CHECK_ARG(I < (1ll << 31), "miq_let_rowquant_fwd: matrix too wide");
     if (int rc = let_check("miq_let_rowquant_fwd", a)) return rc;
     MIQ_CHECK_ARG(out && scale_out && rzp_out && is_aligned16(out), "miq_let_rowquant_fwd: null or unaligned output");
@@ -484,7 +481,7 @@ extern "C" int miq_let_rowquant_bwd(const void* grad_out, const float* g_wshift,
                                     float* d_cs, float* d_rs, float* d_shift, float* d_up, float* d_low, float* workspace,
                                     int64_t O, int64_t I, int n_bits, int symmetric, int flags, int grad_dtype, void* stream) {
     if (O == 0 || I == 0) return 0;
-    LetArgs a{w, cs, rs, rs_div, shift, up, low, (flags >> 1) & 1, n_bits, symmetric, O, (int)I};
+    LetArgs a{w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, O, (int)I};
     MIQ_CHECK_ARG(I < (1ll << 31), "miq_let_rowquant_bwd: matrix too wide");
     if (int rc = let_check("miq_let_rowquant_bwd", a)) return rc;
     MIQ_CHECK_ARG(grad_out && is_aligned16(grad_out), "miq_let_rowquant_bwd: null or unaligned grad_out");

@@ -25,7 +25,6 @@ struct MixArgs {
     int symmetric;
     int hard;
     float threshold;
-    int preact;
 };
 
 struct Grid {
@@ -57,7 +56,7 @@ __device__ __forceinline__ void make_grid(Grid& gr, float b, float w, const MixC
 
 __device__ __forceinline__ MixCtx mix_ctx(const MixArgs& a, long long row, float rmin, float rmax) {
     MixCtx c;
-    c.clip = lwc_clip<float>(a.up, a.low, a.preact, row, rmin, rmax);
+    c.clip = lwc_clip<float>(a.up, a.low, row, rmin, rmax);
     float n = a.n_bits[row];
     if (a.hard) {
         const float t = n + a.threshold;
@@ -249,7 +248,7 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
     }
     if (lane == 0) {
         if (d_nbits) d_nbits[row] = d_n;
-        if (a.up) write_lwc_grads<float>(d_up, d_low, a.preact, row, c.clip, rmin, rmax, d_xmax, d_xmin);
+        if (a.up) write_lwc_grads<float>(d_up, d_low, row, rmin, rmax, d_xmax, d_xmin);
     }
     if (dx) {
         if (at_extreme) {
@@ -327,7 +326,6 @@ static int launch_mix(bool backward, const void* gout, const void* x, const void
     a.symmetric = symmetric;
     a.hard = hard;
     a.threshold = threshold;
-    a.preact = (flags >> 1) & 1;
     if (!backward) MIQ_ROW_LAUNCH(k_mix_fwd, float, vec_ok, geo, stream, a, geo, (float*)out_or_dx);
     else MIQ_ROW_LAUNCH(k_mix_bwd, float, vec_ok, geo, stream, a, geo, (const float*)gout, (float*)out_or_dx, (float*)d_up,
                         (float*)d_low, (float*)d_nbits);
@@ -386,7 +384,6 @@ static int launch_mix_batch(bool backward, int n, const void* const* gout, const
     a.symmetric = symmetric;
     a.hard = hard;
     a.threshold = threshold;
-    a.preact = (flags >> 1) & 1;
     const int npack = vec_ok ? geo.g / 4 : geo.g;
     MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
 #define LAUNCH_ONE(KERN, VECN, TEAM, NV)                                                                          \

@@ -15,13 +15,12 @@ namespace miq {
 template <typename T>
 struct UniArgs {
     const T* x;
-    const T* up;            // [n_rows] raw LWC factors or nullptr
+    const T* up;            // [n_rows] activated LWC factors sigmoid(upbound_factor) / sigmoid(lowbound_factor), or nullptr
     const T* low;
     const float* row_bits;  // [n_rows] per-row integer bit-width (float) or nullptr
     int n_bits;
     int symmetric;
     int clamp_asym;         // clamp the asymmetric scale to [1e-5, 1e4] (fixed mixed-bit quantizer only)
-    int preact;             // up/low already hold sigmoid(factor); gradients are returned w.r.t. those
 };
 
 struct UniCtx {
@@ -47,10 +46,6 @@ __device__ __forceinline__ UniCtx uniform_ctx(const UniArgs<T>& a, long long row
     if (a.up) {
         c.su = to_f<T>(a.up[row]);
         c.sl = to_f<T>(a.low[row]);
-        if (!a.preact) {
-            c.su = sigmoid_t<T>(c.su);
-            c.sl = sigmoid_t<T>(c.sl);
-        }
         c.xmax = rnd<T>(c.su * rmax);
         c.xmin = rnd<T>(c.sl * rmin);
     }
@@ -188,7 +183,7 @@ k_uniform_fwd_bits_batch(UniBatch<T> b, BatchBits bits, UniArgs<T> a, RowGeom ge
 //   asym:   d_range = dS/qmax (masked by the scale clamp when it is active)
 //           d_xmax = d_range, d_xmin = -d_range
 //   sym:    d_amax = mask*dS/(2^(n-1)-1), routed to |xmax| or |xmin| (half each on a tie), times sign
-//   LWC:    d_up = d_xmax*rowmax*su*(1-su), d_low = d_xmin*rowmin*sl*(1-sl)
+//   LWC:    d_su = d_xmax*rowmax, d_sl = d_xmin*rowmin (gradients of the activated factors su, sl)
 //   and the row max/min elements of x receive d_xmax*su / d_xmin*sl, split evenly among ties
 //   (zero padding counts as a tie candidate and swallows its share).
 template <typename T, int VEC, int TEAM, int NV, bool WANT_DX>
@@ -266,10 +261,8 @@ __device__ __forceinline__ void uniform_bwd_row(const UniArgs<T>& a, const RowGe
         d_xmin = -d_range;
     }
     if (a.up && lane == 0) {
-        const float ju = a.preact ? 1.f : c.su * (1.f - c.su);
-        const float jl = a.preact ? 1.f : c.sl * (1.f - c.sl);
-        d_up[row] = from_f<T>(d_xmax * rmax * ju);
-        d_low[row] = from_f<T>(d_xmin * rmin * jl);
+        d_up[row] = from_f<T>(d_xmax * rmax);   // w.r.t. the activated factors
+        d_low[row] = from_f<T>(d_xmin * rmin);
     }
     if (WANT_DX) {
         const float share_max = (d_xmax * c.su) / acc[1];
@@ -373,7 +366,6 @@ static int launch_uniform(bool backward, const void* gout, const void* x, const 
     a.n_bits = n_bits;
     a.symmetric = symmetric;
     a.clamp_asym = flags & 1;
-    a.preact = (flags >> 1) & 1;
     const int npack = vec_ok ? geo.g / N : geo.g;
     MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register-tile capacity (%d packs)",
                   name, geo.g, kRowMaxPacks);
@@ -475,7 +467,6 @@ static int launch_uniform_batch(bool backward, int n, const void* const* gout, c
     a.n_bits = n_bits;
     a.symmetric = symmetric;
     a.clamp_asym = flags & 1;
-    a.preact = (flags >> 1) & 1;
     const int npack = vec_ok ? geo.g / N : geo.g;
     MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register-tile capacity", name, geo.g);
 #define LAUNCH_FWD(VECN, TEAM, NV)                                                                                  \

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("MIQ_LIB") or os.path.join(_HERE, "libmiq.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "miq.h"))
 
 F32, F16 = 0, 1
+MIN_VERSION = 300  # include/miq.h: up / low are the activated clip factors
 _DT = {torch.float32: F32, torch.float16: F16}
 
 _lib = None
@@ -35,6 +36,10 @@ def lib() -> ctypes.CDLL:
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.miq_last_error.restype = ctypes.c_char_p
         _lib.miq_version.restype = ctypes.c_int
+        if _lib.miq_version() < MIN_VERSION:
+            # entry points keep their names when an argument changes meaning: only the version tells a stale build
+            raise MiqError(f"{LIB_PATH} implements interface version {_lib.miq_version()}, this package needs "
+                           f">= {MIN_VERSION}: rebuild it with `make -C llm-quantization_amd/csrc`")
         _lib.miq_act_workspace.restype = ctypes.c_int64
         _lib.miq_act_static_capacity.restype = ctypes.c_int64
         _lib.miq_act_fresh_workspace.restype = ctypes.c_int64

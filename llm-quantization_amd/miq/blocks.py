@@ -144,7 +144,7 @@ class _BlockBase(nn.Module):
         (the exponent quantizer v2, the learnable and the fixed mixed-bit quantizers) with the same settings and row width
         share one kernel launch."""
         from . import functional as F
-        from .quantizer import UniformAffineQuantizer
+        from .quantizer import UniformAffineQuantizer, lwc_clip_factors
         from .quantizer_exp_v2 import ExpAffineQuantizer as Exp2Quantizer
         from .quantizer_mix import MixAffineQuantizer
         from .quantizer_mix_v2 import Mix2AffineQuantizer
@@ -187,7 +187,7 @@ class _BlockBase(nn.Module):
             for m, src in members:
                 flat.append(src)
                 if lwc:
-                    flat += [m.weight_quantizer.upbound_factor, m.weight_quantizer.lowbound_factor]
+                    flat += list(lwc_clip_factors(m.weight_quantizer, src))
             res = F.UniformRowFQBatch.apply(n_bits, sym, lwc, *flat)
             for j, (m, _src) in enumerate(members):
                 m.temp_weight = res[3 * j]
@@ -201,7 +201,7 @@ class _BlockBase(nn.Module):
             for m, src in members:
                 flat.append(src)
                 if lwc:
-                    flat += [m.weight_quantizer.upbound_factor, m.weight_quantizer.lowbound_factor]
+                    flat += list(lwc_clip_factors(m.weight_quantizer, src))
             res = F.Exp2RowFQBatch.apply(n_bits, lwc, *flat)
             for j, (m, _src) in enumerate(members):
                 m.temp_weight = res[2 * j]
@@ -219,7 +219,7 @@ class _BlockBase(nn.Module):
                     q.n_bits.data = q.n_bits.data.clamp(2, 8)  # as MixAffineQuantizer.forward does before use
                 flat += [src, q.n_bits]
                 if lwc:
-                    flat += [q.upbound_factor, q.lowbound_factor]
+                    flat += list(lwc_clip_factors(q, src))
             res = F.MixRowFQBatch.apply(sym, hard, threshold, lwc, *flat)
             for j, (m, _src) in enumerate(members):
                 m.temp_weight = res[j]
@@ -234,7 +234,7 @@ class _BlockBase(nn.Module):
                 bits.append(q._row_bits(src))
                 flat.append(src)
                 if lwc:
-                    flat += [q.upbound_factor, q.lowbound_factor]
+                    flat += list(lwc_clip_factors(q, src))
             res = F.Mix2RowFQBatch.apply(sym, lwc, bits, *flat)
             for j, (m, _src) in enumerate(members):
                 m.temp_weight = res[j]
@@ -282,6 +282,15 @@ class _BlockBase(nn.Module):
     def _smooth_and_quant_temporary(self):
         """The training-step form of the block's LET plan followed by the weight quantizers (reference
         smooth_and_quant_temporary, models/int_opt_layer.py:404-444, models/int_llama_layer.py:279-307)."""
+        # the clipping factors of all weight quantizers are activated in one pass for this step
+        from .quantizer import clear_lwc_activations, set_lwc_activations
+        touched = set_lwc_activations([m.weight_quantizer for _n, m in self.quant_linears()])
+        try:
+            self._smooth_and_quant_temporary_step()
+        finally:
+            clear_lwc_activations(touched)
+
+    def _smooth_and_quant_temporary_step(self):
         if self.let:
             self._truncate_scales()
             plan = self.let_plan()

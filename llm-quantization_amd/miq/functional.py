@@ -28,16 +28,53 @@ def _rows_of(x: torch.Tensor, group: int, padded: bool):
     return x.numel() // group, group, 0, x.numel() // group
 
 
-def _flags(clamp_asym: bool, preactivated: bool) -> int:
-    return (1 if clamp_asym else 0) | (2 if preactivated else 0)
+def _flags(clamp_asym: bool) -> int:
+    return 1 if clamp_asym else 0
+
+
+class LwcSigmoid(torch.autograd.Function):
+    """apply(f_0, f_1, ...) -> (sigmoid(f_0), sigmoid(f_1), ...) for learnable-clipping factors of one dtype on one
+    device.  The kernels take ACTIVATED clip factors: the sigmoid is the routine the reference itself runs
+    (``self.sigmoid(self.upbound_factor)``, quantize/quantizer.py:259-261 -- ATen's), so the clip factor, and with it
+    the scale of every row, is the reference's bit for bit; the backward is ATen's sigmoid_backward on the gradients
+    the kernels return for the activated factors.  All tensors go through ONE concatenated buffer: two launches each
+    way however many quantizers a block holds."""
+
+    @staticmethod
+    def forward(ctx, *fs):
+        sizes = [f.numel() for f in fs]
+        flat = fs[0].reshape(-1) if len(fs) == 1 else torch.cat([f.reshape(-1) for f in fs])
+        act = torch.sigmoid(flat)
+        ctx.save_for_backward(act)
+        ctx.sizes = sizes
+        ctx.set_materialize_grads(False)
+        return tuple(a.view(f.shape) for a, f in zip(act.split(sizes), fs))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        (act,) = ctx.saved_tensors
+        if all(g is None for g in gs):
+            return (None,) * len(gs)
+        parts = [(g.reshape(-1) if g is not None else act.new_zeros(n)) for g, n in zip(gs, ctx.sizes)]
+        gflat = parts[0] if len(parts) == 1 else torch.cat(parts)
+        d = torch.ops.aten.sigmoid_backward(gflat.to(act.dtype), act)
+        return tuple(v.view(g.shape) if g is not None else None for v, g in zip(d.split(ctx.sizes), gs))
+
+
+def lwc_activate(factors):
+    """[sigmoid(f) for f in factors] through LwcSigmoid (differentiable; factors of one dtype and device)."""
+    factors = list(factors)
+    if not factors:
+        return []
+    return list(LwcSigmoid.apply(*factors))
 
 
 def rowquant_uniform_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0,
                          row_bits: Optional[torch.Tensor] = None, clamp_asym: bool = False,
-                         want_codes: bool = False, preactivated: bool = False):
+                         want_codes: bool = False):
     """Returns (out, scale[rows,1], rzp[rows,1], codes|None).
 
-    ``preactivated``: up/low already hold sigmoid(factor) (see MIQ_LWC_PREACTIVATED in miq.h).
+    ``up`` / ``low`` hold the ACTIVATED clip factors sigmoid(factor) (lwc_activate); gradients come back for those.
     """
     dev = L.check_gpu(x, up, low, row_bits)
     O, I, g, rows = _rows_of(x, group, up is not None)
@@ -52,14 +89,13 @@ def rowquant_uniform_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, gro
     with L.on_device(dev):
         L.call("miq_rowquant_uniform_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(row_bits), L.ptr(out),
                L.ptr(scale), L.ptr(rzp), L.ptr(codes), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)),
-               L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)), L.i32(L.dtype_code(x)),
+               L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym)), L.i32(L.dtype_code(x)),
                L.stream_of(x))
     return out, scale, rzp, codes
 
 
 def rowquant_uniform_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0,
-                         row_bits=None, clamp_asym: bool = False, want_dx: bool = True,
-                         preactivated: bool = False):
+                         row_bits=None, clamp_asym: bool = False, want_dx: bool = True):
     """Returns (dx|None, d_up|None, d_low|None)."""
     dev = L.check_gpu(grad_out, x, up, low, row_bits)
     O, I, g, rows = _rows_of(x, group, up is not None)
@@ -69,7 +105,7 @@ def rowquant_uniform_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low
     with L.on_device(dev):
         L.call("miq_rowquant_uniform_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(row_bits),
                L.ptr(dx), L.ptr(d_up), L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)),
-               L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)), L.i32(L.dtype_code(x)),
+               L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym)), L.i32(L.dtype_code(x)),
                L.stream_of(x))
     return dx, d_up, d_low
 
@@ -105,7 +141,7 @@ def _check_batch(xs, ups, lows, gs=None):
                 raise L.MiqError("every gradient must be a contiguous tensor of its matrix's shape and dtype")
 
 
-def rowquant_uniform_fwd_batch(xs, n_bits: int, symmetric: bool, ups=None, lows=None, preactivated: bool = False):
+def rowquant_uniform_fwd_batch(xs, n_bits: int, symmetric: bool, ups=None, lows=None):
     """Row-wise uniform fake quantization of several [O_i, I] matrices of one width and dtype in one launch.
     Returns (outs, scales, rzps) lists."""
     import ctypes
@@ -120,13 +156,12 @@ def rowquant_uniform_fwd_batch(xs, n_bits: int, symmetric: bool, ups=None, lows=
     with L.on_device(dev):
         L.call("miq_rowquant_uniform_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(outs), _ptr_table(scales), _ptr_table(rzps), O, L.i64(I),
-               L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(xs[0])),
+               L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False)), L.i32(L.dtype_code(xs[0])),
                L.stream_of(xs[0]))
     return outs, scales, rzps
 
 
-def rowquant_uniform_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, lows=None, want_dx: bool = True,
-                               preactivated: bool = False):
+def rowquant_uniform_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, lows=None, want_dx: bool = True):
     """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None) lists."""
     import ctypes
     lwc = ups is not None
@@ -142,7 +177,7 @@ def rowquant_uniform_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, l
         L.call("miq_rowquant_uniform_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(dxs) if want_dx else None, _ptr_table(d_ups if lwc else none),
                _ptr_table(d_lows if lwc else none), O, L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
-               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+               L.i32(_flags(False)), L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
     return dxs, d_ups, d_lows
 
 
@@ -154,8 +189,7 @@ def _check_row_bits(xs, row_bits):
             raise L.MiqError(f"every bit-width vector must be a contiguous float32 tensor of {x.shape[0]} entries")
 
 
-def rowquant_mix2_fwd_batch(xs, row_bits, symmetric: bool, ups=None, lows=None, clamp_asym: bool = True,
-                            preactivated: bool = False):
+def rowquant_mix2_fwd_batch(xs, row_bits, symmetric: bool, ups=None, lows=None, clamp_asym: bool = True):
     """Row-wise uniform fake quantization with per-row integer bit-widths (the fixed mixed-bit quantizer) of several
     [O_i, I] matrices of one width and dtype in one launch.  Returns (outs, scales, rzps) lists; bit-identical to
     rowquant_uniform_fwd(..., row_bits=...) per matrix."""
@@ -171,13 +205,13 @@ def rowquant_mix2_fwd_batch(xs, row_bits, symmetric: bool, ups=None, lows=None, 
     with L.on_device(dev):
         L.call("miq_rowquant_mix2_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(row_bits), _ptr_table(outs), _ptr_table(scales), _ptr_table(rzps), O,
-               L.i64(xs[0].shape[1]), L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)),
+               L.i64(xs[0].shape[1]), L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym)),
                L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
     return outs, scales, rzps
 
 
 def rowquant_mix2_bwd_batch(gs, xs, row_bits, symmetric: bool, ups=None, lows=None, clamp_asym: bool = True,
-                            want_dx: bool = True, preactivated: bool = False):
+                            want_dx: bool = True):
     """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None) lists."""
     import ctypes
     lwc = ups is not None
@@ -193,7 +227,7 @@ def rowquant_mix2_bwd_batch(gs, xs, row_bits, symmetric: bool, ups=None, lows=No
         L.call("miq_rowquant_mix2_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(row_bits), _ptr_table(dxs) if want_dx else None,
                _ptr_table(d_ups if lwc else none), _ptr_table(d_lows if lwc else none), O, L.i64(xs[0].shape[1]),
-               L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym, preactivated)), L.i32(L.dtype_code(xs[0])),
+               L.i32(int(bool(symmetric))), L.i32(_flags(clamp_asym)), L.i32(L.dtype_code(xs[0])),
                L.stream_of(xs[0]))
     return dxs, d_ups, d_lows
 
@@ -1188,7 +1222,7 @@ def let_supported(w, group=0) -> bool:
             and w.shape[1] <= 16384 and w.is_contiguous())
 
 
-def let_rowquant_fwd(w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, preactivated=False, out_dtype=None):
+def let_rowquant_fwd(w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, out_dtype=None):
     dev = L.check_gpu(w, cs, rs, shift, up, low)
     O, I = w.shape
     out = torch.empty_like(w, dtype=out_dtype or w.dtype)
@@ -1198,12 +1232,12 @@ def let_rowquant_fwd(w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, preac
     with L.on_device(dev):
         L.call("miq_let_rowquant_fwd", L.ptr(w), L.ptr(cs), L.ptr(rs), L.i32(int(bool(rs_div))), L.ptr(shift), L.ptr(up),
                L.ptr(low), L.ptr(out), L.ptr(scale), L.ptr(rzp), L.ptr(wshift), L.i64(O), L.i64(I), L.i32(int(n_bits)),
-               L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(out)), L.stream_of(w))
+               L.i32(int(bool(symmetric))), L.i32(_flags(False)), L.i32(L.dtype_code(out)), L.stream_of(w))
     return out, wshift, scale, rzp
 
 
 def let_rowquant_bwd(g, g_wshift, w, cs, rs, rs_div, shift, up, low, n_bits, symmetric, want_cs=True, want_rs=True,
-                     want_shift=True, preactivated=False):
+                     want_shift=True):
     dev = L.check_gpu(g, g_wshift, w, cs, rs, shift, up, low)
     O, I = w.shape
     want_cs = want_cs and cs is not None
@@ -1221,7 +1255,7 @@ def let_rowquant_bwd(g, g_wshift, w, cs, rs, rs_div, shift, up, low, n_bits, sym
         L.call("miq_let_rowquant_bwd", L.ptr(g), L.ptr(g_wshift), L.ptr(w), L.ptr(cs), L.ptr(rs), L.i32(int(bool(rs_div))),
                L.ptr(shift), L.ptr(up), L.ptr(low), L.ptr(d_cs), L.ptr(d_rs), L.ptr(d_shift), L.ptr(d_up), L.ptr(d_low),
                L.ptr(ws), L.i64(O), L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
-               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(g)), L.stream_of(w))
+               L.i32(_flags(False)), L.i32(L.dtype_code(g)), L.stream_of(w))
     return d_cs, d_rs, d_shift, d_up, d_low
 
 
@@ -1274,7 +1308,7 @@ def _check_lwc(x, up, low, rows):
         raise L.MiqError(f"LWC factors must be {rows} values of dtype {x.dtype}")
 
 
-def rowquant_exp2_fwd(x, n_bits: int, up=None, low=None, group: int = 0, preactivated: bool = False):
+def rowquant_exp2_fwd(x, n_bits: int, up=None, low=None, group: int = 0):
     """Returns (out, scale[rows,1])."""
     dev = L.check_gpu(x, up, low)
     O, I, g, rows = _rows_of(x, group, up is not None)
@@ -1283,11 +1317,11 @@ def rowquant_exp2_fwd(x, n_bits: int, up=None, low=None, group: int = 0, preacti
     scale = torch.empty((rows, 1), dtype=x.dtype, device=dev)
     with L.on_device(dev):
         L.call("miq_rowquant_exp2_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(out), L.ptr(scale), L.i64(O), L.i64(I),
-               L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(x)), L.stream_of(x))
+               L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False)), L.i32(L.dtype_code(x)), L.stream_of(x))
     return out, scale
 
 
-def rowquant_exp2_bwd(grad_out, x, n_bits: int, up=None, low=None, group: int = 0, want_dx=True, preactivated=False):
+def rowquant_exp2_bwd(grad_out, x, n_bits: int, up=None, low=None, group: int = 0, want_dx=True):
     dev = L.check_gpu(grad_out, x, up, low)
     O, I, g, rows = _rows_of(x, group, up is not None)
     dx = torch.empty_like(x) if want_dx else None
@@ -1295,12 +1329,12 @@ def rowquant_exp2_bwd(grad_out, x, n_bits: int, up=None, low=None, group: int = 
     d_low = torch.empty_like(low) if low is not None else None
     with L.on_device(dev):
         L.call("miq_rowquant_exp2_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(dx), L.ptr(d_up),
-               L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)),
+               L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(_flags(False)),
                L.i32(L.dtype_code(x)), L.stream_of(x))
     return dx, d_up, d_low
 
 
-def rowquant_exp2_fwd_batch(xs, n_bits: int, ups=None, lows=None, preactivated: bool = False):
+def rowquant_exp2_fwd_batch(xs, n_bits: int, ups=None, lows=None):
     """The exponent (v2) quantizer over several [O_i, I] matrices of one width and dtype in one launch.
     Returns (outs, scales) lists; bit-identical to rowquant_exp2_fwd per matrix."""
     import ctypes
@@ -1314,11 +1348,11 @@ def rowquant_exp2_fwd_batch(xs, n_bits: int, ups=None, lows=None, preactivated: 
     with L.on_device(dev):
         L.call("miq_rowquant_exp2_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(outs), _ptr_table(scales), O, L.i64(I), L.i32(int(n_bits)),
-               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+               L.i32(_flags(False)), L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
     return outs, scales
 
 
-def rowquant_exp2_bwd_batch(gs, xs, n_bits: int, ups=None, lows=None, want_dx: bool = True, preactivated: bool = False):
+def rowquant_exp2_bwd_batch(gs, xs, n_bits: int, ups=None, lows=None, want_dx: bool = True):
     """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None) lists."""
     import ctypes
     lwc = ups is not None
@@ -1332,12 +1366,12 @@ def rowquant_exp2_bwd_batch(gs, xs, n_bits: int, ups=None, lows=None, want_dx: b
     with L.on_device(dev):
         L.call("miq_rowquant_exp2_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(dxs) if want_dx else None, _ptr_table(d_ups) if lwc else None,
-               _ptr_table(d_lows) if lwc else None, O, L.i64(I), L.i32(int(n_bits)), L.i32(_flags(False, preactivated)),
+               _ptr_table(d_lows) if lwc else None, O, L.i64(I), L.i32(int(n_bits)), L.i32(_flags(False)),
                L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
     return dxs, d_ups, d_lows
 
 
-def rowquant_exp1_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0, preactivated=False):
+def rowquant_exp1_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0):
     """Returns (out, scale[rows,1], mid[rows,1]|None)."""
     dev = L.check_gpu(x, up, low)
     O, I, g, rows = _rows_of(x, group, up is not None)
@@ -1347,13 +1381,12 @@ def rowquant_exp1_fwd(x, n_bits: int, symmetric: bool, up=None, low=None, group:
     mid = None if symmetric else torch.empty((rows, 1), dtype=x.dtype, device=dev)
     with L.on_device(dev):
         L.call("miq_rowquant_exp1_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(out), L.ptr(scale), L.ptr(mid), L.i64(O),
-               L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False, preactivated)),
+               L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False)),
                L.i32(L.dtype_code(x)), L.stream_of(x))
     return out, scale, mid
 
 
-def rowquant_exp1_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0, want_dx=True,
-                      preactivated=False):
+def rowquant_exp1_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low=None, group: int = 0, want_dx=True):
     dev = L.check_gpu(grad_out, x, up, low)
     O, I, g, rows = _rows_of(x, group, up is not None)
     dx = torch.empty_like(x) if want_dx else None
@@ -1362,12 +1395,11 @@ def rowquant_exp1_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low=No
     with L.on_device(dev):
         L.call("miq_rowquant_exp1_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(dx), L.ptr(d_up),
                L.ptr(d_low), L.i64(O), L.i64(I), L.i64(g), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
-               L.i32(_flags(False, preactivated)), L.i32(L.dtype_code(x)), L.stream_of(x))
+               L.i32(_flags(False)), L.i32(L.dtype_code(x)), L.stream_of(x))
     return dx, d_up, d_low
 
 
-def rowquant_mix_fwd(x, n_bits_rows, symmetric: bool, up=None, low=None, group: int = 0, hard=False, threshold=0.0,
-                     preactivated=False):
+def rowquant_mix_fwd(x, n_bits_rows, symmetric: bool, up=None, low=None, group: int = 0, hard=False, threshold=0.0):
     dev = L.check_gpu(x, up, low, n_bits_rows)
     if x.dtype != torch.float32 or n_bits_rows.dtype != torch.float32:
         raise L.MiqError("the learnable mixed-bit quantizer is float32 only")
@@ -1379,12 +1411,12 @@ def rowquant_mix_fwd(x, n_bits_rows, symmetric: bool, up=None, low=None, group: 
     with L.on_device(dev):
         L.call("miq_rowquant_mix_fwd", L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(n_bits_rows), L.ptr(out), L.i64(O), L.i64(I),
                L.i64(g), L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)),
-               L.i32(_flags(False, preactivated)), L.i32(L.F32), L.stream_of(x))
+               L.i32(_flags(False)), L.i32(L.F32), L.stream_of(x))
     return out
 
 
 def rowquant_mix_bwd(grad_out, x, n_bits_rows, symmetric: bool, up=None, low=None, group: int = 0, hard=False,
-                     threshold=0.0, want_dx=True, preactivated=False):
+                     threshold=0.0, want_dx=True):
     dev = L.check_gpu(grad_out, x, up, low, n_bits_rows)
     O, I, g, rows = _rows_of(x, group, up is not None)
     dx = torch.empty_like(x) if want_dx else None
@@ -1394,7 +1426,7 @@ def rowquant_mix_bwd(grad_out, x, n_bits_rows, symmetric: bool, up=None, low=Non
     with L.on_device(dev):
         L.call("miq_rowquant_mix_bwd", L.ptr(grad_out), L.ptr(x), L.ptr(up), L.ptr(low), L.ptr(n_bits_rows), L.ptr(dx),
                L.ptr(d_up), L.ptr(d_low), L.ptr(d_n), L.i64(O), L.i64(I), L.i64(g), L.i32(int(bool(symmetric))),
-               L.i32(int(bool(hard))), L.f32(float(threshold)), L.i32(_flags(False, preactivated)), L.i32(L.F32),
+               L.i32(int(bool(hard))), L.f32(float(threshold)), L.i32(_flags(False)), L.i32(L.F32),
                L.stream_of(x))
     return dx, d_up, d_low, d_n
 
@@ -1409,7 +1441,7 @@ def _check_mix_batch(xs, bits):
             raise L.MiqError(f"every n_bits vector must be a contiguous tensor of {x.shape[0]} entries")
 
 
-def rowquant_mix_fwd_batch(xs, bits, symmetric: bool, ups=None, lows=None, hard=False, threshold=0.0, preactivated=False):
+def rowquant_mix_fwd_batch(xs, bits, symmetric: bool, ups=None, lows=None, hard=False, threshold=0.0):
     """The learnable mixed-bit quantizer over several [O_i, I] fp32 matrices of one width in one launch.
     Returns the list of outputs; bit-identical to rowquant_mix_fwd per matrix."""
     import ctypes
@@ -1422,13 +1454,12 @@ def rowquant_mix_fwd_batch(xs, bits, symmetric: bool, ups=None, lows=None, hard=
     with L.on_device(dev):
         L.call("miq_rowquant_mix_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
                _ptr_table(lows) if lwc else None, _ptr_table(bits), _ptr_table(outs), O, L.i64(xs[0].shape[1]),
-               L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)), L.i32(_flags(False, preactivated)),
+               L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)), L.i32(_flags(False)),
                L.i32(L.F32), L.stream_of(xs[0]))
     return outs
 
 
-def rowquant_mix_bwd_batch(gs, xs, bits, symmetric: bool, ups=None, lows=None, hard=False, threshold=0.0, want_dx=True,
-                           preactivated=False):
+def rowquant_mix_bwd_batch(gs, xs, bits, symmetric: bool, ups=None, lows=None, hard=False, threshold=0.0, want_dx=True):
     """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None, d_bits) lists."""
     import ctypes
     lwc = ups is not None
@@ -1445,7 +1476,7 @@ def rowquant_mix_bwd_batch(gs, xs, bits, symmetric: bool, ups=None, lows=None, h
                _ptr_table(lows) if lwc else None, _ptr_table(bits), _ptr_table(dxs) if want_dx else None,
                _ptr_table(d_ups) if lwc else None, _ptr_table(d_lows) if lwc else None, _ptr_table(d_bits), O,
                L.i64(xs[0].shape[1]), L.i32(int(bool(symmetric))), L.i32(int(bool(hard))), L.f32(float(threshold)),
-               L.i32(_flags(False, preactivated)), L.i32(L.F32), L.stream_of(xs[0]))
+               L.i32(_flags(False)), L.i32(L.F32), L.stream_of(xs[0]))
     return dxs, d_ups, d_lows, d_bits
 
 

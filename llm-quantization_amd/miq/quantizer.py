@@ -25,6 +25,44 @@ def round_ste(x: torch.Tensor):
     return (x.round() - x).detach() + x
 
 
+def lwc_clip_factors(q, x):
+    """(sigmoid(upbound_factor), sigmoid(lowbound_factor)) of a row-wise quantizer, or (None, None) without learnable
+    clipping: the tensors the reference forms at quantize/quantizer.py:259-261, evaluated by the same ATen routine, which
+    is what the kernels take.  A block that quantizes all of its weights in one step evaluates the factors of all its
+    quantizers in one pass (set_lwc_activations) and leaves them in ``_lwc_act`` for the duration of that step."""
+    if not q.lwc:
+        return None, None
+    up, low = q.upbound_factor, q.lowbound_factor
+    if up.dtype != x.dtype:
+        raise MiqError(f"LWC factors are {up.dtype} but the tensor is {x.dtype}: call .half()/.float() on the module")
+    act = q.__dict__.get("_lwc_act")
+    if act is not None:
+        return act
+    su, sl = F.lwc_activate([up, low])
+    return su, sl
+
+
+def set_lwc_activations(quantizers):
+    """One LwcSigmoid pass over the clipping factors of every quantizer in ``quantizers`` that has them (grouped by dtype
+    and device); each keeps its pair in ``_lwc_act`` until clear_lwc_activations.  Returns the quantizers touched."""
+    groups = {}
+    for q in quantizers:
+        if getattr(q, "lwc", False) and q.upbound_factor.is_cuda:
+            groups.setdefault((q.upbound_factor.dtype, q.upbound_factor.device), []).append(q)
+    touched = []
+    for qs in groups.values():
+        acts = F.lwc_activate([f for q in qs for f in (q.upbound_factor, q.lowbound_factor)])
+        for i, q in enumerate(qs):
+            q.__dict__["_lwc_act"] = (acts[2 * i], acts[2 * i + 1])
+            touched.append(q)
+    return touched
+
+
+def clear_lwc_activations(quantizers):
+    for q in quantizers:
+        q.__dict__.pop("_lwc_act", None)
+
+
 class UniformAffineQuantizer(nn.Module):
     def __init__(
         self,
@@ -121,12 +159,7 @@ class UniformAffineQuantizer(nn.Module):
 
     # ------------------------------------------------------------------ dynamic, row-wise
     def _lwc_params(self, x):
-        if not self.lwc:
-            return None, None
-        up, low = self.upbound_factor, self.lowbound_factor
-        if up.dtype != x.dtype:
-            raise MiqError(f"LWC factors are {up.dtype} but the tensor is {x.dtype}: call .half()/.float() on the module")
-        return up, low
+        return lwc_clip_factors(self, x)
 
     def _row_dynamic(self, x):
         up, low = self._lwc_params(x)

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from . import functional as F
 from ._lib import MiqError
+from .quantizer import lwc_clip_factors
 
 CLIPMIN = 1e-5
 
@@ -69,10 +70,7 @@ class ExpAffineQuantizer(nn.Module):
         self.qmax = 0
 
     def forward(self, x: torch.Tensor):
-        up = self.upbound_factor if self.lwc else None
-        low = self.lowbound_factor if self.lwc else None
-        if up is not None and up.dtype != x.dtype:
-            raise MiqError(f"LWC factors are {up.dtype} but the tensor is {x.dtype}")
+        up, low = lwc_clip_factors(self, x)
         out, scale, mid = F.Exp1RowFQ.apply(x, up, low, self.n_bits, bool(self.symmetric), int(self.group_size or 0))
         self.scale = scale
         self.zero_point = None if self.symmetric else mid

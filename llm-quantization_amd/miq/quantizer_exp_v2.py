@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from . import functional as F
 from ._lib import MiqError
+from .quantizer import lwc_clip_factors
 
 CLIPMIN = 1e-5
 
@@ -76,10 +77,7 @@ class ExpAffineQuantizer(nn.Module):
     def forward(self, x: torch.Tensor):
         if not 2 <= self.n_bits <= 4:
             raise MiqError(f"exponential quantizer supports 2..4 bits, got {self.n_bits}")
-        up = self.upbound_factor if self.lwc else None
-        low = self.lowbound_factor if self.lwc else None
-        if up is not None and up.dtype != x.dtype:
-            raise MiqError(f"LWC factors are {up.dtype} but the tensor is {x.dtype}")
+        up, low = lwc_clip_factors(self, x)
         out, scale = F.Exp2RowFQ.apply(x, up, low, self.n_bits, int(self.group_size or 0))
         self.scale = scale
         self.zero_point = None

@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from . import functional as F
 from ._lib import MiqError
+from .quantizer import lwc_clip_factors
 
 CLIPMIN = 1e-5
 
@@ -90,8 +91,7 @@ class MixAffineQuantizer(nn.Module):
         n_bits = self.n_bits
         if x.dtype != torch.float32:
             raise MiqError("the learnable mixed-bit quantizer runs in float32 (the calibration loop calls qlayer.float())")
-        up = self.upbound_factor if self.lwc else None
-        low = self.lowbound_factor if self.lwc else None
+        up, low = lwc_clip_factors(self, x)
         return F.MixRowFQ.apply(x, n_bits, up, low, bool(self.symmetric), int(self.group_size or 0),
                                 bool(self.hard_assign), float(self.threshold))
 

@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from . import functional as F
 from ._lib import MiqError
+from .quantizer import lwc_clip_factors
 
 CLIPMIN = 1e-5
 
@@ -78,8 +79,7 @@ class Mix2AffineQuantizer(nn.Module):
             raise MiqError("per-row bit-widths cannot be combined with group_size (one bit-width per output row)")
         if x.dtype != torch.float32:
             raise MiqError("the fixed mixed-bit quantizer runs in float32 (its bit tensor is float32 in the reference)")
-        up = self.upbound_factor if self.lwc else None
-        low = self.lowbound_factor if self.lwc else None
+        up, low = lwc_clip_factors(self, x)
         out, scale, rzp = F.UniformRowFQ.apply(x, up, low, 0, bool(self.symmetric), 0, self._row_bits(x), True)
         return out
 

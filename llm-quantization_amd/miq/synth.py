@@ -85,6 +85,12 @@ def lwc_factors(n: int, seed: int = 3, dtype=torch.float32):
     return up, low
 
 
+def lwc_clips(n: int, seed: int = 3, dtype=torch.float32):
+    """The activated clip factors (sigmoid of lwc_factors): what the row-wise kernels take."""
+    up, low = lwc_factors(n, seed, dtype)
+    return torch.sigmoid(up), torch.sigmoid(low)
+
+
 def activation(shape, seed: int = 2, dtype=torch.float32):
     """randn with per-channel std logspace(-1, 1, C) (shuffled) and per-channel mean offsets."""
     g = gen(seed)

@@ -73,12 +73,15 @@ def _from_groups(y: torch.Tensor, shape, pad: int, group_size: Optional[int]):
     return y
 
 
-def _row_minmax_clipped(rows, up, low):
+def _row_minmax_clipped(rows, up, low, activated=False):
+    """Row extremes after learnable clipping (quantizer.py:256-261).  ``activated``: up / low already hold
+    sigmoid(factor) -- used by tests that evaluate the sigmoid on the device under test, whose last bit may
+    differ from the CPU's, and then need the rest of the op sequence for THOSE clip factors."""
     rmin = rows.amin(-1, keepdim=True)
     rmax = rows.amax(-1, keepdim=True)
     if up is not None:
-        rmax = torch.sigmoid(up) * rmax
-        rmin = torch.sigmoid(low) * rmin
+        rmax = (up if activated else torch.sigmoid(up)) * rmax
+        rmin = (low if activated else torch.sigmoid(low)) * rmin
     return rmin, rmax
 
 
@@ -106,7 +109,7 @@ class RowResult:
 # U1 + U2 (+ M2): uniform row-wise fake quant with learnable weight clipping
 # --------------------------------------------------------------------------------------------
 def uniform_row(x, n_bits, symmetric=False, up=None, low=None, group_size=None,
-                clamp_asym_scale=False) -> RowResult:
+                clamp_asym_scale=False, activated=False) -> RowResult:
     """Row-wise ("per_channel"/"per_token" dynamic) uniform fake quantization.
 
     ``n_bits`` is an int, or a [rows, 1] tensor of per-row integer bit-widths (the fixed mixed-bit
@@ -115,7 +118,7 @@ def uniform_row(x, n_bits, symmetric=False, up=None, low=None, group_size=None,
     (quantizer.py:270-271 overwrites the clamped value), so a constant row divides by zero.
     """
     rows, pad = _as_groups(x, group_size, up is not None)
-    rmin, rmax = _row_minmax_clipped(rows, up, low)
+    rmin, rmax = _row_minmax_clipped(rows, up, low, activated)
     if symmetric:
         amax = torch.max(rmax.abs(), rmin.abs())
         half = 2 ** (n_bits - 1) - 1
@@ -139,9 +142,9 @@ def uniform_row(x, n_bits, symmetric=False, up=None, low=None, group_size=None,
 # --------------------------------------------------------------------------------------------
 # E1: exp/log quantizer v1 (no zero level)
 # --------------------------------------------------------------------------------------------
-def exp1_row(x, n_bits, symmetric=True, up=None, low=None, group_size=None) -> RowResult:
+def exp1_row(x, n_bits, symmetric=True, up=None, low=None, group_size=None, activated=False) -> RowResult:
     rows, pad = _as_groups(x, group_size, up is not None)
-    rmin, rmax = _row_minmax_clipped(rows, up, low)
+    rmin, rmax = _row_minmax_clipped(rows, up, low, activated)
     if symmetric:
         scale = torch.max(rmax.abs(), rmin.abs()).clamp(min=CLIP_LO, max=CLIP_HI)
         mid = None
@@ -211,13 +214,13 @@ class _Exp2FQ(torch.autograd.Function):
         return gqq / scale, d_scale_a + gqq * (-x / scale ** 2), None
 
 
-def exp2_row(x, n_bits, up=None, low=None, group_size=None) -> RowResult:
+def exp2_row(x, n_bits, up=None, low=None, group_size=None, activated=False) -> RowResult:
     """Group handling mirrors the reference: calibration sees the grouped view but the fake-quant
     itself is applied to the un-grouped tensor with the [rows,1] scale broadcast
     (quantizer_exp_v2.py:174-176,186-204), so it is only shape-consistent when group_size is None.
     """
     rows, _pad = _as_groups(x, group_size, up is not None)
-    rmin, rmax = _row_minmax_clipped(rows, up, low)
+    rmin, rmax = _row_minmax_clipped(rows, up, low, activated)
     lo, hi = exp2_levels(n_bits)
     scale = (torch.max(rmax.abs(), rmin.abs()) / (hi - lo)).clamp(min=CLIP_LO, max=CLIP_HI)
     out = _Exp2FQ.apply(x, scale, n_bits)
@@ -230,14 +233,14 @@ def exp2_row(x, n_bits, up=None, low=None, group_size=None) -> RowResult:
 # M1: learnable per-row bit-width (FracBits blend of floor/ceil bit-widths)
 # --------------------------------------------------------------------------------------------
 def mix_row(x, n_bits_param, symmetric=False, up=None, low=None, group_size=None,
-            hard=False, threshold=0.0) -> RowResult:
+            hard=False, threshold=0.0, activated=False) -> RowResult:
     """``n_bits_param`` [rows,1] float; the caller is expected to have clamped it to [2, 8]
     (the reference clamps ``.data`` in place at the top of forward, quantizer_mix.py:145)."""
     n = n_bits_param
     if hard:
         n = _ste(torch.round, n + threshold)
     rows, pad = _as_groups(x, group_size, up is not None)
-    rmin, rmax = _row_minmax_clipped(rows, up, low)
+    rmin, rmax = _row_minmax_clipped(rows, up, low, activated)
     n_lo = _ste(torch.floor, n)
     n_hi = _ste(torch.ceil, n)
     q_lo = 2 ** n_lo - 1

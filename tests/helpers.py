@@ -40,6 +40,12 @@ def weight_inputs(meta, groups=None):
     return x, up, low, w
 
 
+def gpu_sigmoid(*ts):
+    """torch.sigmoid evaluated on the GPU (what a module running there computes, and what the reference would), back on the
+    CPU: the clip factors the oracle needs to restate the module's arithmetic for."""
+    return tuple(None if t is None else torch.sigmoid(t.to("cuda:0")).cpu() for t in ts)
+
+
 def same(a: torch.Tensor, b: torch.Tensor) -> bool:
     """Bitwise equality of values, NaNs compare equal (payload/sign of NaN ignored)."""
     if a.shape != b.shape or a.dtype != b.dtype:

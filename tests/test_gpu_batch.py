@@ -25,7 +25,7 @@ def test_batch_equals_single_calls(dt, I, rows, lwc, sym, bits):
     gs = [synth.grad_like(x.cpu(), 90 + i).to(DEV) for i, x in enumerate(xs)]
     ups = lows = None
     if lwc:
-        pairs = [synth.lwc_factors(o, 100 + i, dtype) for i, o in enumerate(rows)]
+        pairs = [synth.lwc_clips(o, 100 + i, dtype) for i, o in enumerate(rows)]
         ups = [p[0].to(DEV) for p in pairs]
         lows = [p[1].to(DEV) for p in pairs]
     outs, scales, rzps = F.rowquant_uniform_fwd_batch(xs, bits, sym, ups, lows)
@@ -47,7 +47,7 @@ def test_batch_equals_single_calls(dt, I, rows, lwc, sym, bits):
 def test_batch_autograd_function():
     I = 256
     xs = [synth.weight(o, I, 120 + i).to(DEV).requires_grad_(True) for i, o in enumerate((64, 96))]
-    pairs = [synth.lwc_factors(o, 130 + i) for i, o in enumerate((64, 96))]
+    pairs = [synth.lwc_clips(o, 130 + i) for i, o in enumerate((64, 96))]
     ups = [p[0].to(DEV).requires_grad_(True) for p in pairs]
     lows = [p[1].to(DEV).requires_grad_(True) for p in pairs]
     flat = []
@@ -105,7 +105,7 @@ def test_exp2_batch_equals_single_matrix_calls(dt, lwc):
     gs = [synth.grad_like(x.cpu(), 80 + i).to(DEV) for i, x in enumerate(xs)]
     ups = lows = None
     if lwc:
-        fac = [synth.lwc_factors(o, 90 + i, dtype) for i, o in enumerate(rows)]
+        fac = [synth.lwc_clips(o, 90 + i, dtype) for i, o in enumerate(rows)]
         ups, lows = [f[0].to(DEV) for f in fac], [f[1].to(DEV) for f in fac]
     outs, scales = F.rowquant_exp2_fwd_batch(xs, 3, ups, lows)
     for want_dx in (True, False):
@@ -187,7 +187,7 @@ def test_mix_batch_equals_single_matrix_calls(sym, hard, I, rows, lwc):
     bits = [synth.mix_bits(o, 3.0, 190 + i).to(DEV) for i, o in enumerate(rows)]
     ups = lows = None
     if lwc:
-        fac = [synth.lwc_factors(o, 200 + i) for i, o in enumerate(rows)]
+        fac = [synth.lwc_clips(o, 200 + i) for i, o in enumerate(rows)]
         ups, lows = [f[0].to(DEV) for f in fac], [f[1].to(DEV) for f in fac]
     outs = F.rowquant_mix_fwd_batch(xs, bits, sym, ups, lows, hard=hard, threshold=0.1)
     for want_dx in (True, False):
@@ -231,7 +231,7 @@ def test_mix_batch_autograd_function_equals_per_matrix_function():
     rows = (64, 96)
     xs = [synth.weight(o, I, 220 + i).to(DEV).requires_grad_(True) for i, o in enumerate(rows)]
     bits = [synth.mix_bits(o, 3.0, 230 + i).to(DEV).requires_grad_(True) for i, o in enumerate(rows)]
-    fac = [synth.lwc_factors(o, 240 + i) for i, o in enumerate(rows)]
+    fac = [synth.lwc_clips(o, 240 + i) for i, o in enumerate(rows)]
     ups = [f[0].to(DEV).requires_grad_(True) for f in fac]
     lows = [f[1].to(DEV).requires_grad_(True) for f in fac]
     flat = []
@@ -262,7 +262,7 @@ def test_mix2_batch_equals_single_matrix_calls(dt, I, rows, lwc, sym):
     bits = [synth.mix2_bits(o, 290 + i).to(DEV) for i, o in enumerate(rows)]
     ups = lows = None
     if lwc:
-        fac = [synth.lwc_factors(o, 300 + i, dtype) for i, o in enumerate(rows)]
+        fac = [synth.lwc_clips(o, 300 + i, dtype) for i, o in enumerate(rows)]
         ups, lows = [f[0].to(DEV) for f in fac], [f[1].to(DEV) for f in fac]
     outs, scales, rzps = F.rowquant_mix2_fwd_batch(xs, bits, sym, ups, lows)
     for want_dx in (True, False):

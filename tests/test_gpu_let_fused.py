@@ -71,20 +71,19 @@ def test_let_fused_matches_chain(O_, I, cs, rs, shift, lwc, sym, bits):
         loss = loss + (wshift_ref * d["gb"]).sum()
     params = [v for v in leaf.values() if v is not None]
     grads = dict(zip([k for k, v in leaf.items() if v is not None], torch.autograd.grad(loss, params))) if params else {}
-    # ---- fused kernels, clipping factors pre-activated
+    # ---- fused kernels (they take the activated clipping factors)
     dev = lambda x: None if x is None else x.to(DEV)
     su = torch.sigmoid(d["up"]) if lwc else None
     sl = torch.sigmoid(d["low"]) if lwc else None
     out, wshift, scale, rzp = F.let_rowquant_fwd(dev(d["w"]), dev(d["cs"]), dev(d["rs"]), rs == "div", dev(d["shift"]),
-                                                 dev(su), dev(sl), bits, sym, preactivated=True)
+                                                 dev(su), dev(sl), bits, sym)
     assert same(scale.cpu(), res.scale.detach()), "scale"
     assert same(rzp.cpu(), res.rzp.detach()), "rounded zero point"
     assert same(out.cpu(), res.out.detach()), "quantized weight"
     if shift:
         assert rel_err(wshift.cpu(), wshift_ref.detach()) <= (1e-6 if I <= 4096 else 3e-6)  # fp32 dot products, other order
     d_cs, d_rs, d_shift, d_su, d_sl = F.let_rowquant_bwd(dev(d["g"]), dev(d["gb"]) if shift else None, dev(d["w"]), dev(d["cs"]),
-                                                         dev(d["rs"]), rs == "div", dev(d["shift"]), dev(su), dev(sl), bits, sym,
-                                                         preactivated=True)
+                                                         dev(d["rs"]), rs == "div", dev(d["shift"]), dev(su), dev(sl), bits, sym)
     if cs:
         assert rel_err(d_cs.cpu(), grads["cs"]) <= 2e-5, rel_err(d_cs.cpu(), grads["cs"])
     if rs:
@@ -100,6 +99,7 @@ def test_let_fused_matches_chain(O_, I, cs, rs, shift, lwc, sym, bits):
 def test_autograd_function_and_fallback_predicate():
     d = make(256, 512, True, "div", True, True, 777)
     w = d["w"].to(DEV)
+    d["up"], d["low"] = torch.sigmoid(d["up"]), torch.sigmoid(d["low"])  # both paths below take activated factors
     p = {k: d[k].to(DEV).requires_grad_(True) for k in ("cs", "rs", "shift", "up", "low")}
     out, wshift, scale, rzp = F.LetRowFQ.apply(w, p["cs"], p["rs"].view(-1, 1), True, p["shift"], p["up"], p["low"], 4, False)
     loss = (out * d["g"].to(DEV)).sum() + (wshift * d["gb"].to(DEV)).sum()
@@ -120,7 +120,8 @@ def test_half_output_and_half_gradient_are_casts():
     gradients of the same values in fp32 (the kernels convert on load)."""
     d = make(512, 4096, True, "div", True, True, 901)
     dev = lambda x: None if x is None else x.to(DEV)
-    args = (dev(d["w"]), dev(d["cs"]), dev(d["rs"]), True, dev(d["shift"]), dev(d["up"]), dev(d["low"]), 4, False)
+    args = (dev(d["w"]), dev(d["cs"]), dev(d["rs"]), True, dev(d["shift"]), dev(torch.sigmoid(d["up"])),
+            dev(torch.sigmoid(d["low"])), 4, False)
     out32, ws32, s32, z32 = F.let_rowquant_fwd(*args)
     out16, ws16, s16, z16 = F.let_rowquant_fwd(*args, out_dtype=torch.float16)
     assert out16.dtype == torch.float16 and torch.equal(out16, out32.half())

@@ -1,7 +1,7 @@
 """Seeded random sweep of shapes, bit-widths and options through the row-wise and the activation kernels against the CPU
 oracle: widths that are not a multiple of the 16-byte pack (the scalar tiles), one-row and one-column matrices, every
 tile of the dispatch tables, groups that do not divide the row, cluster layouts with leftovers.  Forward results must be
-the oracle's bits (clip factors handed over pre-activated, as in the other bit-exact tests)."""
+the oracle's bits (the kernels take activated clip factors: the oracle's own sigmoid values are handed over)."""
 import random
 
 import pytest
@@ -44,9 +44,9 @@ def test_uniform_forward_random_case(i, Orows, I, dt, bits, sym, lwc, group):
     if lwc:
         up, low = synth.lwc_factors(rows, 2000 + i, dtype)
         su, sl = torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)
-    # the oracle applies the sigmoid itself; the kernel receives the same values pre-activated
+    # the oracle applies the sigmoid itself; the kernel receives the same values
     r = O.uniform_row(x, bits, sym, up, low, group or None)
-    out, scale, rzp, codes = F.rowquant_uniform_fwd(x.to(DEV), bits, sym, su, sl, group, want_codes=True, preactivated=lwc)
+    out, scale, rzp, codes = F.rowquant_uniform_fwd(x.to(DEV), bits, sym, su, sl, group, want_codes=True)
     assert same(scale.cpu(), r.scale), "scale"
     assert same(rzp.cpu(), r.rzp), "rounded zero point"
     assert same(out.cpu(), r.out), "dequantized values"
@@ -107,11 +107,11 @@ def test_exponent_grids_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
         up, low = synth.lwc_factors(Orows, 5000 + i, dtype)
         su, sl = torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)
     r2 = O.exp2_row(x, bits, up, low)
-    out2, scale2 = F.rowquant_exp2_fwd(x.to(DEV), bits, su, sl, preactivated=lwc)
+    out2, scale2 = F.rowquant_exp2_fwd(x.to(DEV), bits, su, sl)
     assert same(scale2.cpu(), r2.scale)
     check_exp_forward(x, r2.scale, out2, r2.out, 2)
     r1 = O.exp1_row(x, bits, sym, up, low)
-    out1, scale1, _ = F.rowquant_exp1_fwd(x.to(DEV), bits, sym, su, sl, preactivated=lwc)
+    out1, scale1, _ = F.rowquant_exp1_fwd(x.to(DEV), bits, sym, su, sl)
     assert same(scale1.cpu(), r1.scale)
     check_exp_forward(x if sym else x - r1.rzp, r1.scale, out1, r1.out, 1)
 
@@ -127,7 +127,7 @@ def test_mixed_bit_and_let_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
     nb = synth.mix_bits(Orows, 3.0, 8000 + i)
     for hard in (False, True):
         r = O.mix_row(x, nb.clone(), sym, up, low, None, hard, 0.0)
-        out = F.rowquant_mix_fwd(x.to(DEV), nb.reshape(-1).to(DEV), sym, su, sl, 0, hard, 0.0, preactivated=lwc)
+        out = F.rowquant_mix_fwd(x.to(DEV), nb.reshape(-1).to(DEV), sym, su, sl, 0, hard, 0.0)
         assert same(out.cpu(), r.out), ("mix", hard)
     if I <= 16384:
         cs = torch.rand(I, generator=g) * 2 + 0.25
@@ -136,8 +136,7 @@ def test_mixed_bit_and_let_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
             t = x * cs.view(1, -1)
             t = t / rs.view(-1, 1) if mode == "div" else t * rs.view(-1, 1)
             res = O.uniform_row(t, bits + 1, sym, up, low)
-            out, _, scale, rzp = F.let_rowquant_fwd(x.to(DEV), cs.to(DEV), rs.to(DEV), mode == "div", None, su, sl, bits + 1, sym,
-                                                    preactivated=lwc)
+            out, _, scale, rzp = F.let_rowquant_fwd(x.to(DEV), cs.to(DEV), rs.to(DEV), mode == "div", None, su, sl, bits + 1, sym)
             assert same(scale.cpu(), res.scale) and same(rzp.cpu(), res.rzp) and same(out.cpu(), res.out), ("let", mode)
 
 
@@ -160,13 +159,17 @@ def test_exponent_grids_backward_at_every_tile(I, dt):
         r = O.exp2_row(xg, 3, pu, pl) if kind == 2 else O.exp1_row(xg, 3, True, pu, pl)
         g = torch.autograd.grad((r.out * w).sum(), [xg, pu, pl])
         if kind == 2:
-            out = F.rowquant_exp2_fwd(x.to(DEV), 3, su, sl, preactivated=True)[0]
-            dx, d_su, d_sl = F.rowquant_exp2_bwd(w.to(DEV), x.to(DEV), 3, su, sl, preactivated=True)
+            out = F.rowquant_exp2_fwd(x.to(DEV), 3, su, sl)[0]
+            dx, d_su, d_sl = F.rowquant_exp2_bwd(w.to(DEV), x.to(DEV), 3, su, sl)
         else:
-            out = F.rowquant_exp1_fwd(x.to(DEV), 3, True, su, sl, preactivated=True)[0]
-            dx, d_su, d_sl = F.rowquant_exp1_bwd(w.to(DEV), x.to(DEV), 3, True, su, sl, preactivated=True)
-        if not same(out.cpu(), r.out.detach()):
-            continue  # a level flipped at a threshold: the gradients of that element differ by construction
-        assert masked_rel(dx, g[0]) <= tol_x, (kind, masked_rel(dx, g[0]))
-        assert masked_rel(chain(d_su, su), g[1]) <= tol_p, (kind, "up", masked_rel(chain(d_su, su), g[1]))
-        assert masked_rel(chain(d_sl, sl), g[2]) <= tol_p, (kind, "low", masked_rel(chain(d_sl, sl), g[2]))
+            out = F.rowquant_exp1_fwd(x.to(DEV), 3, True, su, sl)[0]
+            dx, d_su, d_sl = F.rowquant_exp1_bwd(w.to(DEV), x.to(DEV), 3, True, su, sl)
+        # a level that flipped at a threshold changes the gradients of its ROW by construction (the element's own, the
+        # row's scale gradient and with it the shares of the extremes): such rows are left out, every other row is checked
+        ref_out = r.out.detach()
+        rows_ok = ((out.cpu() == ref_out) | (torch.isnan(out.cpu()) & torch.isnan(ref_out))).all(dim=1)
+        assert rows_ok.float().mean().item() >= 0.75, (kind, "levels flipped in too many rows", int((~rows_ok).sum()))
+        assert masked_rel(dx.cpu()[rows_ok], g[0][rows_ok]) <= tol_x, (kind, masked_rel(dx.cpu()[rows_ok], g[0][rows_ok]))
+        du, dl = chain(d_su, su), chain(d_sl, sl)
+        assert masked_rel(du[rows_ok], g[1][rows_ok]) <= tol_p, (kind, "up", masked_rel(du[rows_ok], g[1][rows_ok]))
+        assert masked_rel(dl[rows_ok], g[2][rows_ok]) <= tol_p, (kind, "low", masked_rel(dl[rows_ok], g[2][rows_ok]))

@@ -1,26 +1,26 @@
-"""GPU parity of the uniform row-wise kernels (C ABI through ctypes) against the golden vectors
-captured from the reference and against the CPU oracle at the benchmark sizes.
+"""GPU parity of the uniform row-wise kernels (C ABI through ctypes) and of the UniformAffineQuantizer module that
+calls them, against the golden vectors captured from the reference and against the CPU oracle at the benchmark sizes.
 
-Parity contract.  With pre-activated clip factors (MIQ_LWC_PREACTIVATED: the test hands the kernel
-the same sigmoid values the reference computed) and without LWC everything is a pure function of
-IEEE ops and must be BIT-IDENTICAL to the reference: scale, zero point, integer codes, dequantized
-values.  With the sigmoid fused into the kernel its last bit depends on the math library (ATen's CPU
-sigmoid itself uses a 2-ulp exp), so:
-  * per-row scale within 4 ulp of the reference, and bit-identical for >= 97% of the rows;
-  * on rows whose (scale, zero point) are bit-identical: dequantized values and integer codes are
-    bit-identical to the reference;
-  * on the remaining rows: integer codes are bit-identical to what the reference's op sequence
-    yields for the kernel's own (scale, zero point), and dequantized values are within 1 ulp... of
-    (codes - zp) * scale evaluated with that scale (i.e. the only difference is the scale's last bit);
-  * gradients: norm-wise relative error <= 1e-5 * max(1, qmax/15) in fp32 (the reference sums
-    g*xd and g*m*x/s separately, so its own rounding error grows with qmax); 2e-2 in fp16 (the reference accumulates the row sums in fp16).
+Parity contract.  The library takes ACTIVATED clip factors (sigmoid(upbound_factor), sigmoid(lowbound_factor): the
+tensors the reference forms at quantize/quantizer.py:259-261), so everything it computes is a pure function of IEEE ops
+and must be BIT-IDENTICAL to the reference: scale, zero point, integer codes, dequantized values.
+  * kernel level: handed the reference's own clip factors (torch.sigmoid on the CPU, as in the golden run), the kernels
+    must reproduce the golden vectors bit for bit;
+  * module level: the module evaluates torch.sigmoid on the GPU -- the routine the reference itself would run there --
+    and must be bit-identical to the reference op sequence for those clip factors (the oracle with the GPU's
+    sigmoid values); on every row where the GPU's and the CPU's sigmoid agree (in practice all of them) that is the
+    golden vector itself;
+  * gradients: norm-wise relative error <= 1e-5 * max(1, qmax/15) in fp32 (the reference sums g*xd and g*m*x/s
+    separately, so its own rounding error grows with qmax); 2e-2 in fp16 (the reference accumulates the row sums in
+    fp16).
 """
 import pytest
 import torch
 
-from helpers import DT, golden, rel_err, same, ulp_diff, weight_inputs
+from helpers import DT, golden, gpu_sigmoid, rel_err, same, weight_inputs
 from miq import functional as F
 from miq import synth
+from miq.quantizer import UniformAffineQuantizer
 from oracle import miq_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -33,47 +33,57 @@ def _rowify(t, rows):
 
 
 def check_exact(out, scale, rzp, codes, ref_out, ref_scale, ref_rzp, ref_codes):
-    assert same(scale.cpu(), ref_scale), "scale not bit-identical"
-    assert same(rzp.cpu(), ref_rzp), "zero point not bit-identical"
-    assert same(out.cpu(), ref_out), "dequantized values not bit-identical"
+    assert same(scale.detach().cpu().reshape(ref_scale.shape), ref_scale), "scale not bit-identical"
+    assert same(rzp.detach().cpu().reshape(ref_rzp.shape), ref_rzp), "zero point not bit-identical"
+    assert same(out.detach().cpu(), ref_out), "dequantized values not bit-identical"
     if codes is not None:
         assert torch.equal(codes.cpu().to(torch.int32), torch.nan_to_num(ref_codes.float(), nan=0.0).to(torch.int32))
 
 
-def check_forward(x, up, low, out, scale, rzp, codes, ref_out, ref_scale, ref_rzp, ref_codes, n_bits, group, lwc):
-    out, scale, rzp = out.cpu(), scale.cpu(), rzp.cpu()
-    codes = codes.cpu() if codes is not None else None
-    assert scale.shape == ref_scale.shape
-    ud = ulp_diff(scale, ref_scale).flatten()
-    assert ud.max().item() <= 4, f"scale differs by {ud.max().item()} ulp"
-    row_ok = (ud == 0) & (ulp_diff(rzp, ref_rzp).flatten() == 0)
-    frac = row_ok.float().mean().item()
-    assert frac >= 0.97, f"only {frac:.3f} of the rows have a bit-identical scale"
-    rows = scale.numel()
-    O_, I_ = x.shape
-    padded = bool(group) and lwc and (I_ % group != 0)
-    if padded:
-        # per-(row, group) masks need the padded view; compare whole matrix when everything matched
-        if bool(row_ok.all()):
-            assert same(out, ref_out)
-            if codes is not None:
-                assert torch.equal(codes.to(torch.int32), ref_codes.to(torch.int32))
-        return frac
-    o2, r2 = _rowify(out, rows), _rowify(ref_out, rows)
-    assert same(o2[row_ok], r2[row_ok]), "dequantized values differ on rows with identical scale"
-    if codes is not None:
-        c2, rc2 = _rowify(codes, rows).to(torch.int32), _rowify(ref_codes, rows).to(torch.int32)
-        assert torch.equal(c2[row_ok], rc2[row_ok]), "codes differ on rows with identical scale"
-    bad = ~row_ok
-    if bool(bad.any()):
-        xs = _rowify(x, rows)[bad]
-        s, z = scale.reshape(rows, 1)[bad], rzp.reshape(rows, 1)[bad]
-        q = xs / s
-        lv = ((q.round() - q) + q).add(z).clamp(0, 2 ** n_bits - 1)
-        if codes is not None:
-            assert torch.equal(torch.nan_to_num(lv, nan=0.0).to(torch.int32), _rowify(codes, rows).to(torch.int32)[bad])
-        assert same(lv.sub(z).mul(s), o2[bad])
-    return frac
+def masked(a, ref):
+    """rel_err where the reference is finite: where its own autograd overflows (fp16 s*s underflow, constant rows) it
+    returns NaN / inf; the kernel evaluates the closed form in fp32 and stays finite there."""
+    ok = torch.isfinite(ref)
+    z = torch.zeros_like(ref)
+    return rel_err(torch.where(ok, a.detach().cpu().to(ref.dtype), z), torch.where(ok, ref, z))
+
+
+def module_for(x, bits, sym, group, lwc, up=None, low=None):
+    """The drop-in module as a QuantLinear builds it for a weight (quantize/int_linear.py:47-58), on the GPU."""
+    q = UniformAffineQuantizer(n_bits=bits, symmetric=sym, per_channel_axes=[0], metric="minmax", dynamic=True,
+                               dynamic_method="per_channel", group_size=group or None, shape=tuple(x.shape), lwc=lwc)
+    q = (q.half() if x.dtype == torch.float16 else q).to(DEV)
+    if lwc:
+        with torch.no_grad():
+            q.upbound_factor.copy_(up)
+            q.lowbound_factor.copy_(low)
+    return q
+
+
+def check_module(x, w, bits, sym, group, lwc, up, low, golden_case=None, tol=None):
+    """forward() of the module on the GPU: bit-identical to the reference op sequence (scale, zero point, dequantized
+    values); gradients through the module's own autograd path (ATen sigmoid backward included) to tolerance."""
+    q = module_for(x, bits, sym, group, lwc, up, low)
+    xg = x.to(DEV).requires_grad_(True)
+    y = q(xg)
+    su, sl = gpu_sigmoid(up, low) if lwc else (None, None)
+    r = O.uniform_row(x, bits, sym, su, sl, group or None, activated=True)
+    check_exact(y, q.scale, q.round_zero_point, None, r.out, r.scale, r.rzp, None)
+    if golden_case is not None and lwc and not golden_case["meta"]["big"]:
+        # rows whose clip factors the GPU's sigmoid and the CPU's agree on are the golden rows themselves
+        agree = (su == torch.sigmoid(up)) & (sl == torch.sigmoid(low))
+        if bool(agree.all()):
+            check_exact(y, q.scale, q.round_zero_point, None, golden_case["out"], golden_case["scale"], golden_case["rzp"], None)
+        else:
+            rows = agree.numel()
+            if y.numel() % rows == 0 and not (group and x.shape[1] % group):
+                ok = agree.flatten()
+                assert same(_rowify(y.detach().cpu(), rows)[ok], _rowify(golden_case["out"], rows)[ok])
+        assert agree.float().mean().item() >= 0.9, "the device sigmoid disagrees with the CPU's on more than a few rows"
+    if w is not None:
+        (y.float() * w.to(DEV).float()).sum().backward()
+        return q, xg
+    return q, xg
 
 
 @pytest.mark.parametrize("name", sorted(golden("uniform").keys()))
@@ -83,27 +93,21 @@ def test_uniform_golden(name):
     x, up, low, w = weight_inputs(m)
     group, bits, sym, lwc = m["group_size"], m["n_bits"], m["symmetric"], m["lwc"]
     xd = x.to(DEV)
-    upd = up.to(DEV).contiguous() if lwc else None
-    lowd = low.to(DEV).contiguous() if lwc else None
-    out, scale, rzp, codes = F.rowquant_uniform_fwd(xd, bits, sym, upd, lowd, group, want_codes=bits <= 8)
+    su, sl = (torch.sigmoid(up), torch.sigmoid(low)) if lwc else (None, None)  # the reference's own clip factors
+    sud = su.to(DEV).contiguous() if lwc else None
+    sld = sl.to(DEV).contiguous() if lwc else None
+    out, scale, rzp, codes = F.rowquant_uniform_fwd(xd, bits, sym, sud, sld, group, want_codes=bits <= 8)
     if m["big"]:
         r = O.uniform_row(x, bits, sym, up, low, group or None)
         ref_out, ref_codes = r.out, r.codes
         assert synth.sha(ref_out) == d["out_sha"]  # oracle == reference on this case
     else:
         ref_out, ref_codes = d["out"], d["codes"]
-    if lwc:
-        check_forward(x, up, low, out, scale, rzp, codes, ref_out, d["scale"], d["rzp"], ref_codes, bits, group, lwc)
-        su, sl = torch.sigmoid(up), torch.sigmoid(low)  # the reference's own clip factors
-        o2, s2, z2, c2 = F.rowquant_uniform_fwd(xd, bits, sym, su.to(DEV), sl.to(DEV), group, want_codes=bits <= 8,
-                                                preactivated=True)
-        check_exact(o2, s2, z2, c2, ref_out, d["scale"], d["rzp"], ref_codes)
-    else:
-        check_exact(out, scale, rzp, codes, ref_out, d["scale"], d["rzp"], ref_codes)
+    check_exact(out, scale, rzp, codes, ref_out, d["scale"], d["rzp"], ref_codes)
 
     # backward
     wd = w.to(DEV)
-    dx, d_up, d_low = F.rowquant_uniform_bwd(wd, xd, bits, sym, upd, lowd, group)
+    dx, d_su, d_sl = F.rowquant_uniform_bwd(wd, xd, bits, sym, sud, sld, group)
     tol = (1e-5 if x.dtype == torch.float32 else 2e-2) * max(1.0, (2 ** bits - 1) / 15)
     if m["big"]:
         xg = x.clone().requires_grad_(True)
@@ -113,22 +117,20 @@ def test_uniform_golden(name):
         ref_dx = g[0]
     else:
         ref_dx = d["dx"]
-    # where the reference's own autograd overflows (fp16 s*s underflow, constant rows) it returns
-    # NaN/inf; the kernel evaluates the closed form in fp32 and stays finite there: compare the rest.
-    def masked(a, ref):
-        ok = torch.isfinite(ref)
-        z = torch.zeros_like(ref)
-        return rel_err(torch.where(ok, a.cpu(), z), torch.where(ok, ref, z))
-
     if lwc:
-        assert masked(d_up, d["d_up"]) <= tol, ("d_up", masked(d_up, d["d_up"]))
-        assert masked(d_low, d["d_low"]) <= tol, ("d_low", masked(d_low, d["d_low"]))
-        # pre-activated mode returns d/d(sigmoid): chain with sigmoid' on the host
-        _, d_su, d_sl = F.rowquant_uniform_bwd(wd, xd, bits, sym, su.to(DEV), sl.to(DEV), group, want_dx=False,
-                                               preactivated=True)
+        # the kernel returns d / d(activated factor): chain with sigmoid' on the host
         assert masked(d_su.cpu().float() * (su * (1 - su)).float(), d["d_up"].float()) <= tol
         assert masked(d_sl.cpu().float() * (sl * (1 - sl)).float(), d["d_low"].float()) <= tol
+        _, d_su2, d_sl2 = F.rowquant_uniform_bwd(wd, xd, bits, sym, sud, sld, group, want_dx=False)
+        assert same(d_su2.cpu(), d_su.cpu()) and same(d_sl2.cpu(), d_sl.cpu())
     assert masked(dx, ref_dx) <= 4 * tol, masked(dx, ref_dx)
+
+    # the module's own call path: forward bit-exact, gradients through ATen's sigmoid backward
+    q, xg = check_module(x, w, bits, sym, group, lwc, up, low, golden_case=d)
+    assert masked(xg.grad, ref_dx) <= 4 * tol, masked(xg.grad, ref_dx)
+    if lwc:
+        assert masked(q.upbound_factor.grad, d["d_up"]) <= tol, masked(q.upbound_factor.grad, d["d_up"])
+        assert masked(q.lowbound_factor.grad, d["d_low"]) <= tol, masked(q.lowbound_factor.grad, d["d_low"])
 
 
 @pytest.mark.parametrize("shape,dt,bits,sym,group", [
@@ -148,19 +150,17 @@ def test_uniform_vs_oracle_benchmark_shapes(shape, dt, bits, sym, group):
     rows = shape[0] * (-(-shape[1] // group) if group else 1)
     up, low = synth.lwc_factors(rows, 3, dtype)
     r = O.uniform_row(x, bits, sym, up, low, group or None)
-    out, scale, rzp, codes = F.rowquant_uniform_fwd(x.to(DEV), bits, sym, up.to(DEV), low.to(DEV), group, want_codes=True)
-    check_forward(x, up, low, out, scale, rzp, codes, r.out, r.scale, r.rzp, r.codes, bits, group, True)
     su, sl = torch.sigmoid(up), torch.sigmoid(low)
-    o2, s2, z2, c2 = F.rowquant_uniform_fwd(x.to(DEV), bits, sym, su.to(DEV), sl.to(DEV), group, want_codes=True,
-                                            preactivated=True)
+    o2, s2, z2, c2 = F.rowquant_uniform_fwd(x.to(DEV), bits, sym, su.to(DEV), sl.to(DEV), group, want_codes=True)
     check_exact(o2, s2, z2, c2, r.out, r.scale, r.rzp, r.codes)
+    check_module(x, None, bits, sym, group, True, up, low)
 
 
 def test_properties_full_size():
     """Size-independent properties on a Llama-2-7B MLP weight: idempotence of the level grid and
     codes/out consistency computed on the GPU itself."""
     x = synth.weight(11008, 4096, 5).to(DEV)
-    up, low = (t.to(DEV) for t in synth.lwc_factors(11008, 6))
+    up, low = (torch.sigmoid(t).to(DEV) for t in synth.lwc_factors(11008, 6))
     out, scale, rzp, codes = F.rowquant_uniform_fwd(x, 4, False, up, low, 0, want_codes=True)
     assert int(codes.max()) <= 15
     deq = (codes.float() - rzp) * scale
@@ -197,7 +197,10 @@ def test_backward_at_llama_row_widths(I, dt):
     xr, ur, lr = (t.clone().requires_grad_(True) for t in (x, up, low))
     r = O.uniform_row(xr, 4, False, ur, lr)
     ref = torch.autograd.grad((r.out.float() * g.float()).sum(), [xr, ur, lr])
-    dx, d_up, d_low = F.rowquant_uniform_bwd(g.to(DEV), x.to(DEV), 4, False, up.to(DEV), low.to(DEV))
+    su, sl = torch.sigmoid(up), torch.sigmoid(low)
+    dx, d_su, d_sl = F.rowquant_uniform_bwd(g.to(DEV), x.to(DEV), 4, False, su.to(DEV), sl.to(DEV))
+    d_up = d_su.cpu().float() * (su * (1 - su)).float()
+    d_low = d_sl.cpu().float() * (sl * (1 - sl)).float()
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     for a, b, name in zip((dx, d_up, d_low), ref, ("dx", "d_up", "d_low")):
         ok = torch.isfinite(b)

@@ -51,7 +51,7 @@ def weights(shapes, dt, copies):
     sets = []
     for c in range(copies):
         sets.append([(torch.randn(o, i, device=DEV, dtype=dt) * 0.02, torch.randn(o, i, device=DEV, dtype=dt) * 1e-3,
-                      torch.full((o, 1), 4.0, device=DEV, dtype=dt), torch.full((o, 1), 4.0, device=DEV, dtype=dt))
+                      torch.full((o, 1), 0.982, device=DEV, dtype=dt), torch.full((o, 1), 0.982, device=DEV, dtype=dt))
                      for (o, i) in shapes])
     return sets
 

@@ -17,7 +17,7 @@ for (O, I) in ((4096, 4096), (11008, 4096), (4096, 11008), (5120, 5120), (8192, 
     w = torch.randn(O, I, device=dev) * 0.02
     g = torch.randn(O, I, device=dev) * 1e-3
     cs = torch.rand(I, device=dev) + 0.5; rs = torch.rand(O, device=dev) + 0.5; sh = torch.randn(I, device=dev) * 0.1
-    up = torch.full((O, 1), 4.0, device=dev); low = torch.full((O, 1), 4.0, device=dev); gb = torch.randn(O, device=dev)
+    up = torch.full((O, 1), 0.982, device=dev); low = torch.full((O, 1), 0.982, device=dev); gb = torch.randn(O, device=dev)
     tf = timeit(lambda: F.let_rowquant_fwd(w, cs, rs, True, sh, up, low, 4, False))
     tb = timeit(lambda: F.let_rowquant_bwd(g, gb, w, cs, rs, True, sh, up, low, 4, False))
     tu = timeit(lambda: F.rowquant_uniform_bwd(g, w, 4, False, up, low))

@@ -17,7 +17,7 @@ dev = "cuda:0"
 O, I = 4096, 4096
 w = torch.randn(O, I, device=dev) * 0.02
 cs = torch.rand(I, device=dev) + 0.5; rs = torch.rand(O, device=dev) + 0.5; sh = torch.randn(I, device=dev) * 0.1
-up = torch.full((O, 1), 4.0, device=dev); low = torch.full((O, 1), 4.0, device=dev)
+up = torch.full((O, 1), 0.982, device=dev); low = torch.full((O, 1), 0.982, device=dev)
 for half in (False, True):
     od = torch.float16 if half else None
     print("half out" if half else "fp32 out")

@@ -21,8 +21,8 @@ def main():
         for o, i, reps in ((4096, 4096, 3), (11008, 4096, 1), (4096, 11008, 1)):
             x = (torch.randn(o, i, device=DEV) * 0.02).to(dt)
             g = (torch.randn(o, i, device=DEV) * 1e-3).to(dt)
-            up = torch.full((o, 1), 4.0, device=DEV, dtype=dt)
-            low = torch.full((o, 1), 4.0, device=DEV, dtype=dt)
+            up = torch.full((o, 1), 0.982, device=DEV, dtype=dt)
+            low = torch.full((o, 1), 0.982, device=DEV, dtype=dt)
             for _ in range(reps):
                 F.rowquant_uniform_fwd(x, 4, False, up, low)
                 F.rowquant_uniform_bwd(g, x, 4, False, up, low, want_dx=True)
