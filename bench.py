@@ -400,6 +400,99 @@ def run_c4(args, world, rank, dev, rehearsal, barrier):
     print(json.dumps(out))
 
 
+L7 = [(o, c) for _n, o, c in WEIGHTS]
+C34_KERNEL = {"exp2": ("k_exp2_fwd_batch", "k_exp2_bwd_batch"), "exp1": ("k_exp1_fwd", "k_exp1_bwd"),
+              "mix_soft": ("k_mix_fwd_batch", "k_mix_bwd_batch"), "mix_hard": ("k_mix_fwd_batch", "k_mix_bwd_batch"),
+              "mix2": ("k_uniform_fwd_bits_batch", "k_uniform_bwd_bits_batch")}
+
+
+def families_c3_c4(dev, replays=20):
+    """The exponent (v2 and v1, W3, Llama-2-7B matrices) and mixed-bit (learnable soft / hard, fixed; Llama-2-13B
+    matrices) weight quantizers, forward and backward with input gradient, fp32 with learnable clipping: the operator
+    families the timed step does not contain.  One HIP graph per family and direction over the seven matrices of a
+    layer (0.8 / 1.3 GB per operand: several times the 256 MiB Infinity Cache), timed with HIP events around each of
+    `replays` replays; the median replay gives GB/s of algorithmic bytes (forward 2ns, backward 3ns)."""
+    out = {}
+    side = torch.cuda.Stream(device=dev)
+
+    def timed(fn):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            fn()
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fn()
+        ts = []
+        with torch.cuda.stream(side):
+            g.replay()
+            for _ in range(replays):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                g.replay()
+                b.record()
+                ts.append((a, b))
+        side.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ts)
+        return ms[len(ms) // 2] * 1e-3
+
+    def layer(shapes, seed):
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        xs = [torch.randn(o, c, device=dev, generator=gen) * 0.02 for o, c in shapes]
+        gs = [torch.randn(o, c, device=dev, generator=gen) * 1e-3 for o, c in shapes]
+        clips = [synth.lwc_clips(o, seed + 10 + i) for i, (o, _c) in enumerate(shapes)]
+        ups = [u.to(dev) for u, _l in clips]
+        lows = [l.to(dev) for _u, l in clips]
+        widths = {}
+        for i, (_o, c) in enumerate(shapes):
+            widths.setdefault(c, []).append(i)
+        return xs, gs, ups, lows, list(widths.values()), sum(o * c for o, c in shapes) * 4
+
+    def record(name, shapes_tag, fwd, bwd, nbytes, launches):
+        for tag, fn, mult, kern in (("fwd", fwd, 2, C34_KERNEL[name][0]), ("bwd", bwd, 3, C34_KERNEL[name][1])):
+            t = timed(fn)
+            gbs = mult * nbytes / t / 1e9
+            out[f"{name}_{tag}"] = {"kernel": kern, "shapes": shapes_tag, "GBps": round(gbs, 1),
+                                    "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "launches": launches,
+                                    "us_per_launch": round(t / launches * 1e6, 2), "replays": replays}
+
+    # exponent quantizers, W3, the seven Llama-2-7B matrices
+    xs, gs, ups, lows, groups, nbytes = layer(L7, 700)
+    sel = lambda ts, ids: [ts[i] for i in ids]
+    record("exp2", "Llama-2-7B layer (7 matrices), W3, fp32, LWC",
+           lambda: [F.rowquant_exp2_fwd_batch(sel(xs, g), 3, sel(ups, g), sel(lows, g)) for g in groups],
+           lambda: [F.rowquant_exp2_bwd_batch(sel(gs, g), sel(xs, g), 3, sel(ups, g), sel(lows, g)) for g in groups],
+           nbytes, len(groups))
+    record("exp1", "Llama-2-7B layer (7 matrices), W3 symmetric, fp32, LWC",
+           lambda: [F.rowquant_exp1_fwd(x, 3, True, u, l) for x, u, l in zip(xs, ups, lows)],
+           lambda: [F.rowquant_exp1_bwd(g, x, 3, True, u, l) for g, x, u, l in zip(gs, xs, ups, lows)],
+           nbytes, len(xs))
+    del xs, gs, ups, lows
+    torch.cuda.empty_cache()
+    # mixed-bit quantizers, the seven Llama-2-13B matrices
+    shapes13 = [(o, c) for _n, o, c in L13]
+    xs, gs, ups, lows, groups, nbytes = layer(shapes13, 1300)
+    soft = [synth.mix_bits(o, 3.0, 1500 + i).reshape(-1).contiguous().to(dev) for i, (o, _c) in enumerate(shapes13)]
+    hard = [b.round() for b in soft]
+    fixed = [synth.mix2_bits(o, 1600 + i).contiguous().to(dev) for i, (o, _c) in enumerate(shapes13)]
+    for name, bits, is_hard in (("mix_soft", soft, False), ("mix_hard", hard, True)):
+        record(name, "Llama-2-13B layer (7 matrices), n_bits = 3.5 + U(0, 0.25)" + (" rounded" if is_hard else "") + ", fp32, LWC",
+               lambda: [F.rowquant_mix_fwd_batch(sel(xs, g), sel(bits, g), False, sel(ups, g), sel(lows, g), hard=is_hard)
+                        for g in groups],
+               lambda: [F.rowquant_mix_bwd_batch(sel(gs, g), sel(xs, g), sel(bits, g), False, sel(ups, g), sel(lows, g),
+                                                 hard=is_hard, want_dx=True) for g in groups],
+               nbytes, len(groups))
+    record("mix2", "Llama-2-13B layer (7 matrices), 10/80/10 % of rows at 4/3/2 bits, fp32, LWC",
+           lambda: [F.rowquant_mix2_fwd_batch(sel(xs, g), sel(fixed, g), False, sel(ups, g), sel(lows, g)) for g in groups],
+           lambda: [F.rowquant_mix2_bwd_batch(sel(gs, g), sel(xs, g), sel(fixed, g), False, sel(ups, g), sel(lows, g),
+                                              want_dx=True) for g in groups],
+           nbytes, len(groups))
+    del xs, gs, ups, lows
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(threads: int):
     """The CPU oracle (bit-checked against the reference's golden vectors) on a bounded sample of the
     same workload: one [4096,4096] weight forward+backward and one [1,2048,4096] fp32 activation site
@@ -439,7 +532,7 @@ def cpu_baseline(threads: int):
                       f"fwd+bwd on [1,2048,4096] fp32), torch CPU oracle, {dt:.1f} s"}
 
 
-def block_calib(dev, world, rank):
+def block_calib(dev, world, rank, rehearsal=False):
     """Second half of the metric: seconds per layer of the block-calibration loop (GEMMs and attention
     are PyTorch-ROCm, the quantizer ops are the kernels benchmarked above).  Outside the timed region
     of `value`.  One rank: the reference's own published configuration (its committed OPT-125m run
@@ -448,6 +541,10 @@ def block_calib(dev, world, rank):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import bench_block as BB
     from miq.dist import DPContext
+
+    def say(msg):  # progress on stderr: this part runs for a minute without a result line
+        if rank == 0:
+            print(f"[bench] block calibration: {msg}", file=sys.stderr, flush=True)
 
     out = {}
     try:
@@ -462,18 +559,71 @@ def block_calib(dev, world, rank):
                     r["graph_step_refused"] = str(e)[:200]
                     return r
 
+            say("OPT-125m, the reference log's configuration")
             out["reference_log_opt125m_w3exp_a8"] = graph_or_eager(**BB.REFERENCE_LOG)
             # MEASURED at the reference's schedule (128 samples x 20 epochs, run.sh:6) under fp16 autocast, the W4A4
             # default (main.py:274); the fp32 path is measured at 128 samples x 2 epochs (its 20-epoch figure is a projection)
+            say("Llama-2-7B block, fp16 autocast, 128 samples x 20 epochs")
             out["llama2_7b_w4a4_amp_128x20"] = graph_or_eager(model="7b", samples=128, epochs=20, amp=True, act="per_tensor")
+            say("Llama-2-7B block, fp32, 128 samples x 2 epochs")
             out["llama2_7b_w4a4_fp32_128x2"] = BB.run("7b", 128, 2, False, "per_tensor", dev=dev)
-        else:
-            dp = DPContext.from_env()
-            out["llama2_7b_w4a4_fp32"] = BB.run("7b", 4, 2, False, "per_tensor", dev=dev, dp=dp)
-            out["llama2_7b_w4a4_amp"] = BB.run("7b", 4, 2, True, "per_tensor", dev=dev, dp=dp)
+            return out
     except Exception as e:  # the headline line must survive a failure of this auxiliary measurement
         out["error"] = f"{type(e).__name__}: {e}"
+        return out
+    # N ranks.  A rank that failed while the others entered a collective would leave them waiting, so every rank first runs
+    # the whole loop on its own (no collective: this is also the warm-up), then the ranks agree (one MIN all-reduce of
+    # a flag) whether all of them got through, and only then run the data-parallel loops.
+    ok, err = 1, None
+    try:
+        for amp in (False, True):
+            say(f"every rank on its own ({'fp16 autocast' if amp else 'fp32'})")
+            BB.run("7b", 2, 1, amp, "per_tensor", dev=dev, dp=None, warmup=False)
+    except Exception as e:
+        ok, err = 0, f"{type(e).__name__}: {e}"
+        print(f"[bench rank {rank}] local block-calibration run failed: {err}", file=sys.stderr, flush=True)
+    flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearsal else dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        out["error"] = err or "another rank failed in its local warm-up run; the data-parallel runs were skipped on all ranks"
+        return out
+    try:  # (an error every rank raises at the same point, e.g. a bug in this path, must not cost the headline line)
+        dp = DPContext.from_env()
+        say(f"data parallel over {world} ranks, fp32")
+        out["llama2_7b_w4a4_fp32"] = BB.run("7b", 4, 2, False, "per_tensor", dev=dev, dp=dp, warmup=False)
+        say(f"data parallel over {world} ranks, fp16 autocast")
+        out["llama2_7b_w4a4_amp"] = BB.run("7b", 4, 2, True, "per_tensor", dev=dev, dp=dp, warmup=False)
+    except Exception as e:
+        import traceback
+        out["error"] = f"{type(e).__name__}: {e}"
+        print(f"[bench rank {rank}] data-parallel block calibration failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
     return out
+
+
+def launch_ranks(n: int, argv):
+    """`python bench.py --gpus N ...` as the driver calls it: start N ranks of this script on this node through
+    torch.distributed.run in a CHILD process (this process never initialises a GPU), pass rank 0's JSON line through
+    and return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)  # anything else the ranks printed
+    if lines:
+        print(lines[-1])
+    elif proc.returncode == 0:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def main():
@@ -484,19 +634,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block-calib", action="store_true")
     ap.add_argument("--block-calib", action="store_true",
-                    help="with N > 1 ranks: also time the data-parallel block calibration (off by default there: a rank "
-                         "that fails inside it would leave the others waiting in a collective before the result line)")
+                    help="one-GPU rehearsal of N > 1 ranks (MIQ_BENCH_ONE_GPU=1): also run the data-parallel block "
+                         "calibration (it is on by default on real ranks, off in the rehearsal where N blocks share one GPU)")
+    ap.add_argument("--no-families", action="store_true", help="skip the exponent / mixed-bit families object")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
     ap.add_argument("--workload", choices=("c2", "c4"), default="c2",
                     help="c2 (default): the Llama-2-7B W4A4 calibration-step workload the metric is quoted on; c4: Llama-2-13B "
                          "mixed-bit weight quantization with the rows sharded over the ranks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain script: become the launcher.  Nothing has touched the GPU yet in this process.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU")
     # MIQ_BENCH_ONE_GPU=1 is a development aid: all ranks share GPU 0 and talk over gloo, which lets the
     # N > 1 code path be rehearsed on a single-GPU box.  The real launch is one rank per GPU over RCCL.
     rehearsal = os.environ.get("MIQ_BENCH_ONE_GPU") == "1"
@@ -547,8 +701,17 @@ def main():
     launches = wl.launches()
     del wl, fams
     torch.cuda.empty_cache()
-    want_blk = (world == 1 and not args.no_block_calib) or (world > 1 and args.block_calib and not rehearsal)
-    blk = block_calib(dev, world, rank) if want_blk else None
+    fam34 = None
+    if rank == 0 and not args.no_families:
+        try:
+            fam34 = families_c3_c4(dev)
+        except Exception as e:  # the headline line must survive a failure of this auxiliary measurement
+            fam34 = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    if world > 1:
+        barrier()
+    want_blk = not args.no_block_calib and (world == 1 or not rehearsal or args.block_calib)
+    blk = block_calib(dev, world, rank, rehearsal) if want_blk else None
 
     if rank == 0:
         by = by_local
@@ -567,7 +730,7 @@ def main():
         achieved = by[dom] * args.steps / (totals[dom] * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled, WRITE_SIZE as read) of a separate rocprofv3 run of
         # this command by the builder; the file names that run
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_current = None, None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -575,6 +738,9 @@ def main():
             per_step = tj.get(dom)
             traffic = per_step // launches[dom] if per_step else None
             traffic_source = tj.get("_source")
+            # the counters were collected on one build of the kernels: say whether it is the one that just ran
+            from miq import _lib
+            traffic_current = tj.get("_csrc_digest") == _lib.source_digest()
         out = {
             "metric": "fake-quant GB/s (% HBM peak) + OmniQuant block-calib s/layer, Llama-2-7B",
             "value": round(step_bytes * world * args.steps / dt / 1e9, 1),
@@ -597,13 +763,19 @@ def main():
             "frac_hbm_peak": round(step_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": FAMILY_KERNEL[dom], "family": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_source,
+                         "traffic_source": traffic_source, "traffic_measured_on_this_build": traffic_current,
                          "bytes_per_launch": by[dom] // launches[dom],
                          "avg_launch_us": round(totals[dom] * 1e3 / n_launch, 2)},
             "families": fam,
         }
+        if fam34 is not None:
+            out["families_c3_c4"] = fam34
         if blk is not None:
             out["block_calib"] = blk
+        if world > 1:
+            out["config"]["note"] = ("no hardware scaling curve exists in this repository: the multi-GPU numbers are whatever "
+                                     "this run measures" + ("; THIS run is a one-GPU rehearsal over gloo (all ranks share GPU 0): "
+                                                            "functional check only" if rehearsal else ""))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
         print(json.dumps(out))

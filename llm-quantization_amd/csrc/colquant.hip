@@ -9,6 +9,7 @@
 // Semantics: UniformAffineQuantizer.per_cluster_minmax_calibration / per_tensor_minmax_calibration /
 // calibration / fake_quant (reference quantize/quantizer.py:157-238,99-121) and the index_select in
 // OmniLayerNorm.forward (quantize/omni_norm.py:36-40).
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include "miq_common.h"
@@ -784,7 +785,21 @@ static int act_fresh_t(int n, const void* const* x, int64_t cluster_size, const 
     if (vec_ok) {
         // fp32 keeps 8 rows per lane in flight, fp16 (twice the channels per pack, twice the conversions) 4
         constexpr int D = sizeof(T) == 4 ? 8 : 4;
-        if (uniform) hipLaunchKernelGGL((k_colstat_slots<T, N, D, true>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
+        // development knobs (tools/dev): rows per block and loads in flight of the statistics kernel alone; the slot table
+        // makes its grid independent of the quantize kernel's
+        static const int knob_rows = getenv("MIQ_STAT_ROWS") ? atoi(getenv("MIQ_STAT_ROWS")) : 0;
+        static const int knob_depth = getenv("MIQ_STAT_DEPTH") ? atoi(getenv("MIQ_STAT_DEPTH")) : 0;
+        if (uniform && (knob_rows > 0 || knob_depth > 0)) {
+            const int rpc_s = knob_rows > 0 ? knob_rows : rpc;
+            const int nchunk_s = (int)((R + rpc_s - 1) / rpc_s);
+            const int nrep_s = nchunk_s > 16 ? kSlotReplicas : 1;
+            MIQ_CHECK_ARG(nrep_s == nrep, "MIQ_STAT_ROWS: the two kernels must agree on the replica count");
+            const dim3 grid_s(tiles, nchunk_s, n);
+            if ((knob_depth > 0 ? knob_depth : D) == 8)
+                hipLaunchKernelGGL((k_colstat_slots<T, N, 8, true>), grid_s, dim3(256), 0, stream, xs, R, (int)C, rpc_s, sm, ws, ws_stride, nrep);
+            else
+                hipLaunchKernelGGL((k_colstat_slots<T, N, 4, true>), grid_s, dim3(256), 0, stream, xs, R, (int)C, rpc_s, sm, ws, ws_stride, nrep);
+        } else if (uniform) hipLaunchKernelGGL((k_colstat_slots<T, N, D, true>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
         else hipLaunchKernelGGL((k_colstat_slots<T, N, D, false>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
         if (nrep == 1) launch_fresh_quant<T, N, 1>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
         else launch_fresh_quant<T, N, kSlotReplicas>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);

@@ -80,11 +80,17 @@ __device__ __forceinline__ float extreme_at(const float* chan, const void* merge
 // UNIFORM: the channels of a lane's pack share one cluster (equal clusters whose size is a multiple of VEC, merged
 // statistics): one scale / zero point / pair of extremes per lane instead of VEC of each, which is what lets the
 // vectorised kernels stay inside 128 registers without spilling.
-template <typename T, int VEC, bool UNIFORM>
+// LANEPART (with UNIFORM): the lane's pack lies inside one cluster, and a cluster only needs the SUM of dS over its
+// channels and to know WHERE elements equal to its extremes sit.  The block then leaves one {dS, tie bits} pair per lane
+// and row chunk (8 bytes instead of 3 * VEC floats: the three per-channel planes are 6 MB of a [2048, 4096] fp16 slab's
+// 50 MB) and does not count ties at all: a lane whose batch reaches an extreme sets bit 0 (maximum) / bit 1 (minimum) and
+// k_colbwd_pairs looks at the rows of exactly those (row chunk, pack) pairs.
+template <typename T, int VEC, bool UNIFORM, bool LANEPART = false>
 __global__ void __launch_bounds__(256, 4)  // four waves per SIMD: all four blocks of a CU resident
 k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qmax, int flagged) {
+    static_assert(!LANEPART || UNIFORM, "one pair per lane needs the lane's pack inside one cluster");
     constexpr int NP = UNIFORM ? 1 : VEC;  // parameter sets per lane
-    __shared__ float sm[3][4][64 * VEC];
+    __shared__ float sm[LANEPART ? 2 : 3][4][LANEPART ? 64 : 64 * VEC];
     const BwdSlab& sb = slabs.s[blockIdx.z];
     const T* __restrict__ x = static_cast<const T*>(sb.x);
     const T* __restrict__ g = static_cast<const T*>(sb.g);
@@ -101,14 +107,14 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
     if (flagged && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         sb.ws[(3ll * gridDim.y + 5) * C] = 0.f;  // "some cluster left its shares to the correction kernel": set by k_colbwd_cluster
     float acc[VEC];
-    int nmx[VEC], nmn[VEC];
+    int nmx[LANEPART ? 1 : VEC], nmn[LANEPART ? 1 : VEC];
+    int tbits = 0;  // LANEPART: bit 0 / 1: a batch of this lane reached the cluster maximum / minimum
     float s[NP], rs[NP], z[NP], cmn[NP], cmx[NP];
     bool ok = true;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        acc[e] = 0.f;
-        nmx[e] = nmn[e] = 0;
-    }
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < (LANEPART ? 1 : VEC); ++e) nmx[e] = nmn[e] = 0;
     // A wave owns rows r0 + w, r0 + w + 4, ...; it handles them UNR at a time with all 2*UNR loads in
     // flight (a chunk is typically 32 rows: one or two batches per wave).  The first batch is issued before the per-channel parameters are fetched.
     // 32 elements per batch keep the kernel under 128 registers (four waves per SIMD) without spills; larger
@@ -190,14 +196,16 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
             bool tie = false;
 #pragma unroll
             for (int k = 0; k < NP; ++k) tie = tie || bmx[k] == cmx[k] || bmn[k] == cmn[k];
-            if (__any(tie)) {
+            if constexpr (LANEPART) {
+                tbits |= (bmx[0] == cmx[0] ? 1 : 0) | (bmn[0] == cmn[0] ? 2 : 0);
+            } else if (__any(tie)) {
                 // (the rows are read again, from cache, rather than kept in registers for a case this rare)
 #pragma unroll 1
                 for (int u = 0; u < UNR; ++u) {
                     if (r + 4 * u >= r1) break;
                     const Pack<T, VEC> again = ld_pack<T, VEC>(x + (r + 4 * u) * C + col0);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
+                    for (int e = 0; e < (LANEPART ? 1 : VEC); ++e) {
                         const float xv = to_f<T>(again.e[e]);
                         nmx[e] += (xv == cmx[UNIFORM ? 0 : e]) ? 1 : 0;
                         nmn[e] += (xv == cmn[UNIFORM ? 0 : e]) ? 1 : 0;
@@ -220,22 +228,45 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
         else if (no_nan) stream_rows(std::false_type{}, std::false_type{});
         else stream_rows(std::false_type{}, std::true_type{});
     }
+    if constexpr (LANEPART) {
+        // the pack's channels in a fixed tree, then the four waves in a fixed order: one sum per lane and row chunk
+        float a = 0.f;
+        if constexpr (VEC == 8) a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        else if constexpr (VEC == 4) a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        else {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        sm[0][w][lane * VEC + e] = acc[e];
-        sm[1][w][lane * VEC + e] = (float)nmx[e];
-        sm[2][w][lane * VEC + e] = (float)nmn[e];
-    }
-    __syncthreads();
-    if (w == 0 && valid) {
+            for (int e = 0; e < VEC; ++e) a += acc[e];
+        }
+        sm[0][w][lane] = a;
+        sm[1][w][lane] = __int_as_float(tbits);
+        __syncthreads();
+        if (w == 0 && valid) {
+            const int bits = __float_as_int(sm[1][0][lane]) | __float_as_int(sm[1][1][lane]) | __float_as_int(sm[1][2][lane]) |
+                             __float_as_int(sm[1][3][lane]);
+            float2 o;
+            o.x = (sm[0][0][lane] + sm[0][1][lane]) + (sm[0][2][lane] + sm[0][3][lane]);
+            o.y = __int_as_float(bits);
+            const long long P = C / VEC;  // packs per row
+            reinterpret_cast<float2*>(part)[(long long)blockIdx.y * P + (long long)blockIdx.x * 64 + lane] = o;
+        }
+    } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int e = 0; e < VEC; ++e) {
+            sm[0][w][lane * VEC + e] = acc[e];
+            sm[1][w][lane * VEC + e] = (float)nmx[e];
+            sm[2][w][lane * VEC + e] = (float)nmn[e];
+        }
+        __syncthreads();
+        if (w == 0 && valid) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int i = lane * VEC + e;
-                part[((long long)k * gridDim.y + blockIdx.y) * C + col0 + e] =
-                    (sm[k][0][i] + sm[k][1][i]) + (sm[k][2][i] + sm[k][3][i]);
-            }
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int i = lane * VEC + e;
+                    part[((long long)k * gridDim.y + blockIdx.y) * C + col0 + e] =
+                        (sm[k][0][i] + sm[k][1][i]) + (sm[k][2][i] + sm[k][3][i]);
+                }
+        }
     }
 }
 
@@ -527,6 +558,130 @@ k_colbwd_cluster(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_ch
     }
 }
 
+// Second (and last) launch behind k_colbwd_stream<.., LANEPART>: one block per cluster and slab.
+//   fold     the cluster's {dS, tie bits} pairs over all row chunks and its packs, in a fixed order (every thread its
+//            strided entries, then the block tree): nchunk * csize / VEC pairs, a few KB
+//   pairs    (row chunk, pack) entries with a tie bit name the only places where an element can equal a cluster
+//            extreme: their rows are read back and the tied elements counted per channel (integer counts in LDS: the
+//            order of arrival does not matter)
+//   shares   d_kmax = dS / qmax, split over the tied channels and then over the tied rows of a channel (flat: over all
+//            tied elements), as autograd splits amax / amin (d_kmin likewise, negated); masked by the scale clamp
+//   apply    dx += share at those elements: (direct + share_max) + share_min like every other form of this backward
+// More than kPairMax entries (ReLU-style mass ties: every chunk holds a minimum) make the block walk its whole cluster
+// slab instead, once to count and once to apply.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_colbwd_pairs(BwdSlabs slabs, int nchunk, long long R, int C, int rows_per_chunk, int csize, float qmax, int flat) {
+    __shared__ int cnt[2][kClusterMax];
+    __shared__ float lds[64];
+    __shared__ int pairs[kPairMax];
+    __shared__ int npairs;
+    const BwdSlab& sb = slabs.s[blockIdx.z];
+    const float2* __restrict__ plane = reinterpret_cast<const float2*>(sb.ws);
+    const T* __restrict__ x = static_cast<const T*>(sb.x);
+    T* __restrict__ dx = static_cast<T*>(sb.dx);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int st = (int)blockIdx.x * csize;
+    const long long P = C / VEC;
+    const int L = csize / VEC, lane0 = st / VEC;
+    const T kmin_raw = static_cast<const T*>(sb.kmin)[st], kmax_raw = static_cast<const T*>(sb.kmax)[st];  // used after the fold
+    if (tid == 0) npairs = 0;
+    for (int c = tid; c < csize; c += 256) cnt[0][c] = cnt[1][c] = 0;
+    __syncthreads();
+    const int entries = nchunk * L;
+    float acc = 0.f;
+    for (int i0 = tid; i0 < entries; i0 += 256 * 8) {
+        float2 v[8];
+        int jj[8], ll[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // unconditional loads (an entry past the end re-reads the last one and is skipped below)
+            const int i = i0 + 256 * u < entries ? i0 + 256 * u : entries - 1;
+            jj[u] = i / L;
+            ll[u] = i - jj[u] * L;
+            v[u] = plane[(long long)jj[u] * P + lane0 + ll[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + 256 * u >= entries) break;
+            acc += v[u].x;
+            const int bits = __float_as_int(v[u].y);
+            if (bits) {
+                const int k = atomicAdd(&npairs, 1);
+                if (k < kPairMax) pairs[k] = (jj[u] << 12) | (ll[u] << 2) | bits;
+            }
+        }
+    }
+    // block sum in a fixed tree (and a barrier behind the list)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) lds[wv] = acc;
+    __syncthreads();
+    const float dS = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    const int np = npairs;
+    const bool mass = np > kPairMax;
+    const float mn = to_f<T>(kmin_raw), mx = to_f<T>(kmax_raw);
+    // the elements of (row chunk j, pack l) that equal a cluster extreme: f(row, channel inside the cluster, is_max)
+    auto scan_pair = [&](int e, auto f) {
+        const int j = e >> 12, l = (e >> 2) & 1023;
+        const long long r0 = (long long)j * rows_per_chunk;
+        long long r1 = r0 + rows_per_chunk;
+        if (r1 > R) r1 = R;
+        for (long long r = r0 + lane; r < r1; r += 64) {
+            const Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + st + l * VEC);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float xv = to_f<T>(a.e[q]);
+                if ((e & 1) && xv == mx) f(r, l * VEC + q, true);
+                if ((e & 2) && xv == mn) f(r, l * VEC + q, false);
+            }
+        }
+    };
+    auto scan_slab = [&](auto f) {
+        const long long total = R * L;
+        for (long long i = tid; i < total; i += 256) {
+            const long long r = i / L;
+            const int l = (int)(i - r * L);
+            const Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + st + l * VEC);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float xv = to_f<T>(a.e[q]);
+                if (xv == mx) f(r, l * VEC + q, true);
+                if (xv == mn) f(r, l * VEC + q, false);
+            }
+        }
+    };
+    auto count = [&](long long, int c, bool is_max) { atomicAdd(&cnt[is_max ? 0 : 1][c], 1); };
+    if (mass) scan_slab(count);
+    else
+        for (int i = wv; i < np; i += 4) scan_pair(pairs[i], count);
+    __syncthreads();
+    // number of channels that attain each extreme (flat: of elements)
+    int n[2] = {0, 0};
+    for (int c = tid; c < csize; c += 256) {
+        n[0] += flat ? cnt[0][c] : (cnt[0][c] > 0 ? 1 : 0);
+        n[1] += flat ? cnt[1][c] : (cnt[1][c] > 0 ? 1 : 0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n[0] += __shfl_xor(n[0], o); n[1] += __shfl_xor(n[1], o); }
+    if (lane == 0) { lds[8 + wv] = (float)n[0]; lds[16 + wv] = (float)n[1]; }
+    __syncthreads();
+    const float nmax = (lds[8] + lds[9]) + (lds[10] + lds[11]), nmin_ = (lds[16] + lds[17]) + (lds[18] + lds[19]);
+    const float lo = rnd<T>(kClipLo);
+    const float s_raw = rnd<T>(rnd<T>(mx - mn) / qmax);
+    const bool live = s_raw >= lo && s_raw <= kClipHi;
+    const float d = live ? dS / qmax : 0.f;
+    auto apply = [&](long long r, int c, bool is_max) {
+        const float k = (float)cnt[is_max ? 0 : 1][c];
+        const float h = is_max ? (flat ? d / nmax : (d / nmax) / k) : (flat ? -d / nmin_ : (-d / nmin_) / k);
+        // an element that is both (a constant cluster) is visited twice by one lane, maximum first
+        const long long at = r * C + st + c;
+        dx[at] = from_f<T>(to_f<T>(dx[at]) + h);
+    };
+    if (mass) scan_slab(apply);
+    else
+        for (int i = wv; i < np; i += 4) scan_pair(pairs[i], apply);
+}
+
 // eval mode (frozen scales): dx = g * [level inside the grid]
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
@@ -725,6 +880,14 @@ static int colquant_bwd_launch(const BwdSlabs& slabs, int n, bool routed, const 
     // no flag and no correction launch then
     const bool inline_mass = merged && R * (covered / (ncl > 0 ? ncl : 1)) <= kInlineMass;
     const int flagged = merged && !inline_mass ? 1 : 0;
+    if (merged && uniform && vec_ok && phase == 0) {
+        // two launches: per-lane partials, then one block per cluster folds them and corrects the tied elements
+        const int csize = (int)(covered / (ncl > 0 ? ncl : 1));
+        hipLaunchKernelGGL((k_colbwd_stream<T, N, true, true>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, 0);
+        hipLaunchKernelGGL((k_colbwd_pairs<T, N>), dim3(ncl, 1, n), block, 0, stream, slabs, nchunk, R, (int)C, rpc, csize, qmax, flat);
+        MIQ_CHECK_LAUNCH(who);
+        return 0;
+    }
     if (phase != 2) {
         if (vec_ok && uniform) hipLaunchKernelGGL((k_colbwd_stream<T, N, true>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);
         else if (vec_ok) hipLaunchKernelGGL((k_colbwd_stream<T, N, false>), grid, block, 0, stream, slabs, R, (int)C, rpc, qmax, flagged);

@@ -52,6 +52,20 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def source_digest() -> str:
+    """16 hex digits over the kernel sources next to the library (csrc/*.hip, *.h): measurement files record it so that a
+    reader can tell whether they were taken on the build at hand."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+    for path in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def declared_symbols():
     """Function names declared in include/miq.h (used by the ABI completeness test)."""
     with open(HEADER_PATH) as f:

@@ -339,6 +339,12 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
     losses: List[float] = []
     norms: List[float] = []
     graph_steps = 0
+    notes: List[str] = []  # decisions a caller without a logger must still be able to see (a graph step given up, say)
+
+    def note(msg):
+        notes.append(msg)
+        if logger is not None:
+            logger.info(msg)
     if cfg.epochs > 0:
         with torch.no_grad():
             qlayer.float()
@@ -450,8 +456,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                     try:
                         graph, static = capture_step()
                     except RuntimeError as e:  # an operation that cannot be captured (a host synchronisation, say)
-                        if logger is not None:
-                            logger.info(f"{layer_prefix}: the step cannot be captured ({str(e)[:120]}); continuing eagerly")
+                        note(f"{layer_prefix}: the step cannot be captured ({str(e)[:120]}); continuing eagerly")
                         graph = static = None
                         want_graph = False
                         optimizer.zero_grad(set_to_none=True)
@@ -462,8 +467,8 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
                     if same:
                         verified[0] += 1
                     elif verified[0] < 2:
-                        if logger is not None:
-                            logger.info(f"{layer_prefix}: the graph-replayed step differs from the eager step; continuing eagerly")
+                        note(f"{layer_prefix}: the graph-replayed step differs from the eager step at step {done}; "
+                             "continuing eagerly")
                         graph = static = restore = None
                         want_graph = False
                     else:
@@ -510,7 +515,7 @@ def calibrate_layer(qlayer, quant_inps, fp_inps, attention_mask, cfg: CalibConfi
     finalize_layer(qlayer, quant_inps, attention_mask, cfg, dp, position_ids)
     lap("propagate")
     return {"losses": losses, "norms": norms, "indices": indices, "omni_state": qlayer.omni_state_dict(),
-            "seconds": seconds, "graph_steps": graph_steps}
+            "seconds": seconds, "graph_steps": graph_steps, "steps": len(losses), "notes": notes}
 
 
 def finalize_layer(qlayer, quant_inps, attention_mask, cfg: CalibConfig, dp: Optional[DPContext] = None, position_ids=None):

@@ -354,6 +354,11 @@ class ClusterLayout:
         counts = [int(c) for c in counts]
         if any(c < 0 for c in counts) or sum(counts) > C:
             raise L.MiqError(f"cluster sizes {counts[:4]}... do not fit {C} channels")
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # the prefix sums travel to the device by a copy from pageable host memory, which HIP refuses on a capturing
+            # stream (hipErrorStreamCaptureUnsupported) and which invalidates the whole capture
+            raise L.MiqError("a cluster layout is built from host lists and cannot be created during graph capture: run the "
+                             "captured calls once eagerly first (ClusterLayout.get caches the layout)")
         starts = [0]
         for c in counts:
             starts.append(starts[-1] + c)
@@ -499,10 +504,16 @@ _FRESH_WS = {}
 
 def _fresh_workspace(dev, nbytes: int):
     """The statistics table of miq_act_fresh_quant_fwd: zero-filled once, then only ever handed to that function.
-    One per (device, stream): calls that share a table must be ordered on one stream."""
+    One per (device, stream): calls that share a table must be ordered on one stream.  The table is never created or
+    grown while its stream is being captured into a HIP graph: its zero fill would become a graph node (re-run by every
+    replay, never run for later eager calls on that stream) and its memory would belong to the graph's private pool."""
     key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
     ws = _FRESH_WS.get(key)
     if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.MiqError("the activation quantizer's statistics table for this stream does not exist yet (or is too small) "
+                             "and cannot be allocated during graph capture: run the same calls once eagerly ON THE CAPTURE "
+                             "STREAM first (torch.cuda.graph(g, stream=s) after a warm-up under torch.cuda.stream(s))")
         ws = _FRESH_WS[key] = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
     return ws
 

@@ -284,7 +284,9 @@ class UniformAffineQuantizer(nn.Module):
         """Quantize-dequantize with given parameters (reference quantizer.py:99-121).  The layout is read from the
         SHAPE of ``scale``: one element (per tensor), last axis = channels with every other axis 1 (per channel, what
         the static calibration leaves in ``self.scale``), or one value per row / per group with a trailing axis of
-        1 (what per_token_dynamic_calibration leaves).  Anything else is refused rather than guessed."""
+        1 (what per_token_dynamic_calibration leaves).  A quantizer whose rows are zero-padded to a multiple of the group
+        size (``deficiency`` > 0) pads, quantizes and strips like the reference (:100-102, :119-120).  Anything else is
+        refused rather than guessed."""
         C = x.shape[-1]
         if scale.shape != round_zero_point.shape and round_zero_point.numel() != 1:
             raise MiqError(f"scale {tuple(scale.shape)} and zero point {tuple(round_zero_point.shape)} differ in shape")
@@ -292,14 +294,21 @@ class UniformAffineQuantizer(nn.Module):
             s = scale.to(x.dtype).reshape(-1).expand(C).contiguous()
             z = round_zero_point.to(x.dtype).reshape(-1).expand(C).contiguous()
             return F.ActEvalFQ.apply(x, s, z, self.n_bits)
+        pad = int(self.deficiency) if (self.group_size and self.deficiency > 0) else 0
+        xp = x
+        if pad:
+            if x.dim() != 2:
+                raise MiqError("a padded group layout is defined for 2-D weights only")
+            xp = torch.cat((x, x.new_zeros((x.shape[0], pad))), dim=1)
         g = int(self.group_size or C)
-        rows = x.numel() // g if g else 0
-        if scale.dim() >= 1 and scale.shape[-1] == 1 and scale.numel() == rows and x.numel() == rows * g:
+        rows = xp.numel() // g if g else 0
+        if scale.dim() >= 1 and scale.shape[-1] == 1 and scale.numel() == rows and xp.numel() == rows * g:
             # row-wise parameters: the per-channel kernel on the transposed slab (channels <-> rows)
-            xt = x.reshape(rows, g).t().contiguous()
+            xt = xp.reshape(rows, g).t().contiguous()
             s = scale.to(x.dtype).reshape(-1).contiguous()
             z = round_zero_point.to(x.dtype).reshape(-1).expand(rows).contiguous()
-            return F.ActEvalFQ.apply(xt, s, z, self.n_bits).t().reshape(x.shape)
+            out = F.ActEvalFQ.apply(xt, s, z, self.n_bits).t().reshape(xp.shape)
+            return out[:, :-pad] if pad else out
         raise MiqError(f"fake_quant: a scale of shape {tuple(scale.shape)} does not describe a per-tensor, per-channel "
                        f"([..., {C}]) or per-row ([{rows}, 1]) layout of a tensor of shape {tuple(x.shape)}")
 

@@ -139,6 +139,24 @@ def uniform_row(x, n_bits, symmetric=False, up=None, low=None, group_size=None,
     return RowResult(out, scale, rzp, codes)
 
 
+def fake_quant_given(x, scale, rzp, n_bits, group_size=None, deficiency=0):
+    """UniformAffineQuantizer.fake_quant (quantizer.py:99-121) with parameters handed in: zero-pad every row by
+    ``deficiency`` columns, view as groups, round(x / s) + zp -> clamp -> - zp -> * s, undo the view, strip the padding."""
+    xr = x
+    if deficiency > 0:
+        xr = torch.cat((xr, torch.zeros((x.shape[0], deficiency), dtype=x.dtype)), dim=1)
+    shape = xr.shape
+    if group_size:
+        assert xr.dim() == 2
+        xr = xr.reshape(-1, group_size)
+    deq, _codes = _affine_fq(xr, scale, rzp, 2 ** n_bits - 1)
+    if group_size:
+        deq = deq.reshape(shape)
+    if deficiency > 0:
+        deq = deq[:, :-deficiency]
+    return deq
+
+
 # --------------------------------------------------------------------------------------------
 # E1: exp/log quantizer v1 (no zero level)
 # --------------------------------------------------------------------------------------------

@@ -540,6 +540,7 @@ def main():
     fams["block_llama"] = lambda _ref: gen_block_llama(args.ref)
     fams["block_llama_gqa"] = lambda _ref: gen_block_llama_gqa(args.ref)
     fams["act_stats"] = lambda _ref: gen_act_stats(args.ref)
+    fams["fake_quant"] = gen_fake_quant
     for fam, fn in fams.items():
         if args.only and fam not in args.only.split(","):
             continue
@@ -548,6 +549,62 @@ def main():
         torch.save(cases, path)
         print(f"{fam}: {len(cases)} cases -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
+
+
+# ---------------------------------------------------------------------------------------------
+# UniformAffineQuantizer.fake_quant (quantize/quantizer.py:99-121) called on its own with given parameters: row-wise
+# scales of a grouped weight whose rows are zero-padded to a multiple of the group size (deficiency > 0: pad, quantize,
+# strip), row-wise scales without groups, a per-channel vector and a single scale.
+# ---------------------------------------------------------------------------------------------
+def gen_fake_quant(ref):
+    cases = {}
+    Q = ref.uni.UniformAffineQuantizer
+
+    def rowwise(name, shape, dt, bits, group, seed):
+        dtype = DT[dt]
+        x = synth.weight(shape[0], shape[1], seed, dtype)
+        q = Q(n_bits=bits, symmetric=True, per_channel_axes=[0], metric="minmax", dynamic=True, dynamic_method="per_channel",
+              group_size=group, shape=shape, lwc=True)
+        if dtype == F16:
+            q = q.half()
+        with torch.no_grad():
+            q(x)  # leaves scale / round_zero_point of this weight
+            scale, rzp = q.scale.detach().clone(), q.round_zero_point.detach().clone()
+            y = synth.weight(shape[0], shape[1], seed + 1, dtype)  # ANOTHER tensor through the same parameters
+            out = q.fake_quant(y, scale, rzp)
+        cases[name] = {"meta": {"shape": list(shape), "dtype": dt, "n_bits": bits, "group_size": group or 0,
+                                "deficiency": int(q.deficiency), "seed": seed, "kind": "rows"},
+                       "scale": scale, "rzp": rzp, "out": out.clone()}
+
+    for dt in ("f32", "f16"):
+        rowwise(f"fq_{dt}_rows_g64_deficient", (32, 200), dt, 4, 64, 301)    # 200 = 3 * 64 + 8: 56 zero columns appended
+        rowwise(f"fq_{dt}_rows_g128_deficient", (16, 328), dt, 3, 128, 303)
+        rowwise(f"fq_{dt}_rows_g64", (32, 256), dt, 4, 64, 305)
+        rowwise(f"fq_{dt}_rows", (48, 96), dt, 4, None, 307)
+
+    def static(name, shape, dt, bits, per_channel, seed):
+        dtype = DT[dt]
+        x = synth.activation(shape, seed, dtype)
+        g = synth.gen(seed + 1)
+        C = shape[-1]
+        n = C if per_channel else 1
+        scale = (torch.rand(n, generator=g) * 0.2 + 0.01).to(dtype)
+        rzp = torch.randint(0, 2 ** bits, (n,), generator=g).to(dtype)
+        if per_channel:
+            scale, rzp = scale.view(*([1] * (len(shape) - 1)), C), rzp.view(*([1] * (len(shape) - 1)), C)
+        else:
+            scale, rzp = scale.view(()), rzp.view(())
+        q = Q(n_bits=bits, symmetric=False, per_channel_axes=[], metric="minmax", dynamic=False, dynamic_method="per_cluster")
+        with torch.no_grad():
+            out = q.fake_quant(x, scale, rzp)
+        cases[name] = {"meta": {"shape": list(shape), "dtype": dt, "n_bits": bits, "group_size": 0, "deficiency": 0, "seed": seed,
+                                "kind": "channel" if per_channel else "tensor"},
+                       "scale": scale, "rzp": rzp, "out": out.clone()}
+
+    for dt in ("f32", "f16"):
+        static(f"fq_{dt}_channel", (2, 24, 96), dt, 4, True, 311)
+        static(f"fq_{dt}_tensor", (40, 64), dt, 8, False, 313)
+    return cases
 
 
 # ---------------------------------------------------------------------------------------------
@@ -744,10 +801,12 @@ def gen_block_llama(ref_root):
 # models/int_llama_layer.py:130-137), 2 KV heads for 4 query heads.  LET off: the reference's smooth_q_k_*
 # assumes as many KV heads as heads (models/transformation.py:62-69), so only the clipping factors train.
 def gen_block_llama_gqa(ref_root):
-    return {"llama_tiny_gqa_w4a4_nolet": _llama_block_case(kv_heads=2, let=False)}
+    # the second case is the arithmetic of a W4A8 run: 8-bit activations force the fp32 path (main.py:274-275)
+    return {"llama_tiny_gqa_w4a4_nolet": _llama_block_case(kv_heads=2, let=False),
+            "llama_tiny_gqa_w4a8_nolet": _llama_block_case(kv_heads=2, let=False, abits=8)}
 
 
-def _llama_block_case(kv_heads, let):
+def _llama_block_case(kv_heads, let, abits=4):
     import types as _t
     import warnings
 
@@ -760,7 +819,7 @@ def _llama_block_case(kv_heads, let):
 
     H, Fd, heads, T, N, epochs = 64, 160, 4, 32, 4, 2
     hd = H // heads
-    wbits, abits, theta, eps = 4, 4, 10000.0, 1e-5
+    wbits, theta, eps = 4, 10000.0, 1e-5
     g = synth.gen(191)
 
     def lin(i, o):

@@ -56,6 +56,29 @@ def same(a: torch.Tensor, b: torch.Tensor) -> bool:
     return torch.equal(torch.where(an, torch.zeros_like(a), a), torch.where(bn, torch.zeros_like(b), b))
 
 
+def same_act_backward(dx, ref_dx, x, cmin, cmax, why=""):
+    """Two forms of the calibrating activation quantizer's backward that sum the scale gradient in different orders
+    (per-lane partials folded per cluster against per-channel partials folded per channel): every element that is NOT
+    at an extreme of its cluster carries the direct path only and must be bit-identical; the elements at the extremes
+    (the only ones a share of the scale gradient is routed to) must agree to the rounding of the sum -- which also pins
+    the tie counts, since a share divided by a wrong count is off by a factor."""
+    dx, ref_dx, x = dx.detach().cpu(), ref_dx.detach().cpu(), x.detach().cpu()
+    cmin, cmax = cmin.detach().cpu().reshape(1, -1), cmax.detach().cpu().reshape(1, -1)
+    tied = (x == cmax) | (x == cmin)
+    assert same(torch.where(tied, torch.zeros_like(dx), dx), torch.where(tied, torch.zeros_like(ref_dx), ref_dx)), \
+        f"{why}: direct path differs away from the cluster extremes"
+    if bool(tied.any()):
+        a, b = dx[tied].double(), ref_dx[tied].double()
+        ok = torch.isfinite(b)
+        assert torch.equal(torch.isfinite(a), ok), f"{why}: finiteness of the routed elements differs"
+        if bool(ok.any()):
+            # norm-wise, like every gradient bound of these tests (dS is a sum with cancellation over the whole cluster
+            # slab; against the oracle's autograd the routed elements are held to 5e-3)
+            tol = 1e-4 if dx.dtype == torch.float32 else 2e-3
+            err = ((a[ok] - b[ok]).abs().max() / b[ok].abs().max().clamp_min(1e-30)).item()
+            assert err <= tol, f"{why}: routed elements differ by {err:.3g} (tolerance {tol})"
+
+
 def ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Distance in units-in-the-last-place between same-dtype float tensors (NaN==NaN -> 0, sign-aware)."""
     assert a.dtype == b.dtype

@@ -63,13 +63,15 @@ def test_tiny_llama_block_matches_reference_run():
     assert ((qo - d["quant_out"]).abs().mean() / d["quant_out"].abs().mean()).item() <= 5e-2
 
 
-def test_tiny_gqa_llama_block_matches_reference_run():
+@pytest.mark.parametrize("case,abits", [("llama_tiny_gqa_w4a4_nolet", 4), ("llama_tiny_gqa_w4a8_nolet", 8)])
+def test_tiny_gqa_llama_block_matches_reference_run(case, abits):
     """Grouped-query attention (2 key / value heads for 4 query heads: the Llama-2-70B layout, repeat_kv of
     models/int_llama_layer.py:130-137) without LET, against the reference's QuantLlamaDecoderLayer driven by the llama
-    branch of its loop (tests/golden/block_llama_gqa.pt).  Only the clipping factors train."""
-    d = golden("block_llama_gqa")["llama_tiny_gqa_w4a4_nolet"]
+    branch of its loop (tests/golden/block_llama_gqa.pt).  Only the clipping factors train.  The second case is the
+    arithmetic of the Llama-2-70B W4A8 configuration: grouped-query attention AND 8-bit activations (fp32 path)."""
+    d = golden("block_llama_gqa")[case]
     m = d["meta"]
-    assert m["kv_heads"] == 2 and m["heads"] == 4 and not m["let"]
+    assert m["kv_heads"] == 2 and m["heads"] == 4 and not m["let"] and m["abits"] == abits
     q = build(d)
     assert q.self_attn.k_proj.weight.shape == (32, 64)
     quant_inps = d["inps"].clone().to(DEV)

@@ -40,3 +40,53 @@ def test_family_graphs_survive_interleaved_eager_work():
         assert torch.equal(wl.flat, ref), f"step {step}"
     del wl, graphs
     torch.cuda.empty_cache()
+
+
+def test_capture_without_a_warm_statistics_table_is_refused():
+    """The fresh-statistics activation quantizer keeps one statistics table per stream, zero-filled when it is created.
+    Creating it inside a capture would turn the fill into a graph node and put the table into the graph's pool: the call
+    must refuse, and after a warm-up on the capture stream the same capture must go through and replay the eager bits."""
+    from miq import functional as F
+    from miq import synth
+    from miq._lib import MiqError
+    dev = torch.device("cuda:0")
+    x = synth.activation((256, 1024), 61).to(dev)
+    layout = F.ClusterLayout.get([32] * 32, 1024, dev)
+    ref = F.act_fresh_quant_fwd([x], 4, layout)[0][0].clone()
+    side = torch.cuda.Stream(device=dev)          # a stream no call has run on yet: no table
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(MiqError, match="capture"):
+        with torch.cuda.graph(g, stream=side):
+            F.act_fresh_quant_fwd([x], 4, layout)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):                 # warm-up on the capture stream creates the table eagerly
+        F.act_fresh_quant_fwd([x], 4, layout)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = F.act_fresh_quant_fwd([x], 4, layout)[0][0]
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+def test_cluster_layout_cannot_be_built_during_capture():
+    """Its prefix sums are copied from pageable host memory, which a capturing stream refuses (and which invalidates the
+    capture): a clear error instead, and the cached layout of an earlier eager call is fine."""
+    from miq import functional as F
+    from miq._lib import MiqError
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(MiqError, match="capture"):
+        with torch.cuda.graph(g, stream=side):
+            F.ClusterLayout.get([3, 5, 8, 13, 21, 14], 64, dev)   # a layout no earlier test has used
+    torch.cuda.synchronize()
+    warm = F.ClusterLayout.get([3, 5, 8, 13, 21, 14], 64, dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        assert F.ClusterLayout.get([3, 5, 8, 13, 21, 14], 64, dev) is warm
+    torch.cuda.synchronize()

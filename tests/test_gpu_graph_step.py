@@ -1,8 +1,9 @@
 """A calibration step replayed from one HIP graph (CalibConfig.graph_step) must follow the eager trajectory: same
 gradients, hence bit-identical parameters and propagated activations; the loss values agree to summation order (the
-graph path takes the loss kernel instead of ATen's reduction for fp32 operands).  The reordered OPT
-block still routes column sums through ATen reductions, which do not survive graph replay on this ROCm build: its first
-replayed steps are caught by the built-in comparison and the loop continues eagerly, with the same result."""
+graph path takes the loss kernel instead of ATen's reduction for fp32 operands).  ATen's multi-block reductions do not
+survive graph replay on this ROCm build, so no captured step may contain one: the reordered OPT block used to route the
+column sums of its smoothing-scale gradients through one (its replays were caught by the loop's built-in comparison
+and it fell back to eager steps); they go through this library's column-sum kernel now, and the block must REPLAY."""
 import pytest
 import torch
 
@@ -42,7 +43,7 @@ def test_graph_replayed_steps_equal_eager_steps(amp):
     assert torch.equal(out[True][2], out[False][2])
 
 
-def test_a_block_with_aten_reductions_falls_back_to_the_eager_loop():
+def test_the_reordered_opt_block_replays_too():
     import test_gpu_block_calibration as opt
     from miq import reorder_utils as R
     from miq.calibrate import CalibConfig, calibrate_layer, reorder_block
@@ -69,8 +70,11 @@ def test_a_block_with_aten_reductions_falls_back_to_the_eager_loop():
                               dims=(m["H"], m["F"], m["heads"]), indices=indices)
         R.oc_maxmin_dict.clear()
         R.ic_maxmin_dict.clear()
-        out[graph] = (res["losses"], {k: v.clone() for k, v in res["omni_state"].items()}, quant.clone(), res["graph_steps"])
-    # whichever way the comparison went (replayed or fallen back), the result is the eager one
+        out[graph] = (res["losses"], {k: v.clone() for k, v in res["omni_state"].items()}, quant.clone(), res["graph_steps"],
+                      res["notes"])
+    steps = m["epochs"] * m["N"]
+    # one eager step, two steps run both ways and compared, every other step replayed; nothing given up on the way
+    assert out[False][3] == 0 and out[True][3] == steps - 3 and out[True][4] == [], (out[True][3], out[True][4])
     assert torch.allclose(torch.tensor(out[True][0]), torch.tensor(out[False][0]), rtol=1e-6, atol=0)
     for k, v in out[False][1].items():
         assert torch.equal(v, out[True][1][k]), k

@@ -241,3 +241,26 @@ def test_degenerate_rows_match_the_oracle(dt, sym, width):
         outs, scales, rzps = F.rowquant_uniform_fwd_batch([x.to(DEV), x.flip(0).contiguous().to(DEV)], bits, sym)
         assert same(outs[0].cpu(), r.out) and same(outs[1].cpu(), r.out.flip(0))
         assert same(scales[0].cpu(), r.scale) and same(rzps[0].cpu(), r.rzp)
+
+
+@pytest.mark.parametrize("name", sorted(golden("fake_quant").keys()))
+def test_public_fake_quant_matches_the_reference(name):
+    """UniformAffineQuantizer.fake_quant(x, scale, round_zero_point) called on its own (quantize/quantizer.py:99-121):
+    row-wise parameters of a grouped weight, including rows that are zero-padded to a multiple of the group size
+    (deficiency > 0: pad, quantize, strip), row-wise without groups, a per-channel vector and a single scale.  Bit-identical
+    to the reference's method on the same tensors."""
+    d = golden("fake_quant")[name]
+    m = d["meta"]
+    shape, dtype = tuple(m["shape"]), DT[m["dtype"]]
+    if m["kind"] == "rows":
+        x = synth.weight(shape[0], shape[1], m["seed"] + 1, dtype)
+        q = UniformAffineQuantizer(n_bits=m["n_bits"], symmetric=True, per_channel_axes=[0], dynamic=True,
+                                   dynamic_method="per_channel", group_size=m["group_size"] or None, shape=shape, lwc=True)
+        assert q.deficiency == m["deficiency"]
+    else:
+        x = synth.activation(shape, m["seed"], dtype)
+        q = UniformAffineQuantizer(n_bits=m["n_bits"], dynamic=False, dynamic_method="per_cluster")
+    out = q.fake_quant(x.to(DEV), d["scale"].to(DEV), d["rzp"].to(DEV))
+    assert out.shape == x.shape
+    assert same(out.cpu(), d["out"])
+    assert same(O.fake_quant_given(x, d["scale"], d["rzp"], m["n_bits"], m["group_size"] or None, m["deficiency"]), d["out"])

@@ -204,6 +204,21 @@ def test_act_stats_oracle_matches_reference_functions(name):
         assert same(scales[key], d["scales"][key]) and same(shifts[key], d["shifts"][key]), key
 
 
+def _fq_input(m):
+    shape, dtype = tuple(m["shape"]), DT[m["dtype"]]
+    if m["kind"] == "rows":
+        return synth.weight(shape[0], shape[1], m["seed"] + 1, dtype)
+    return synth.activation(shape, m["seed"], dtype)
+
+
+@pytest.mark.parametrize("name", sorted(golden("fake_quant").keys()))
+def test_fake_quant_with_given_parameters(name):
+    d = golden("fake_quant")[name]
+    m = d["meta"]
+    out = O.fake_quant_given(_fq_input(m), d["scale"], d["rzp"], m["n_bits"], m["group_size"] or None, m["deficiency"])
+    assert same(out, d["out"])
+
+
 def test_allocate_bits_rule():
     s = torch.tensor([0.5, 0.1, 0.9, 0.3, 0.7, 0.2, 0.8, 0.4, 0.6, 0.05])
     assert O.allocate_bits(s).tolist() == [3, 3, 4, 3, 3, 3, 3, 3, 3, 2]

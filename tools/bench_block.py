@@ -99,7 +99,10 @@ def run(model="7b", samples=4, epochs=2, amp=False, act="per_tensor", wbits=4, a
         "model": (f"Llama-2-{model}" if is_llama else model) + " block", "seq_len": seq, "samples_per_rank": samples, "epochs": epochs, "ranks": dp.world,
         "w_bits": wbits, "a_bits": abits, "weight_quantizer": "exp-v2" if wexp else "uniform", "w_symmetric": wsym,
         "act_quant": act, "let": let, "precision": "fp16 autocast" if amp else "fp32",
-        "step": "HIP graph replay (forward + loss + backward), optimizer eager" if graph else "eager",
+        # what RAN, not what was asked for: a step that could not be captured or did not reproduce the eager step falls back
+        "step": ("HIP graph replay (forward + loss + backward), optimizer eager" if res["graph_steps"] > 0 else
+                 ("eager (graph replay was requested and given up: see notes)" if graph else "eager")),
+        "graph_steps": res["graph_steps"], "steps": res["steps"], "notes": res["notes"],
         "s_per_step": round(s_step, 5), "s_fp_targets_per_sample": round(sec["fp_targets"] / samples, 5),
         "s_propagate_per_sample": round(sec["propagate"] / (samples * dp.world), 5),
         "loss_first": res["losses"][0], "loss_last": res["losses"][-1],

@@ -29,10 +29,15 @@ L13 = [(5120, 5120)] * 4 + [(13824, 5120)] * 2 + [(5120, 13824)]
 
 
 def time_graph(fn, reps=7):
-    fn()
+    # warm up ON the capture stream: per-stream state of the library (the activation kernels' statistics table) must
+    # exist before the capture, which refuses to allocate it
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):
         fn()
     g.replay()
     torch.cuda.synchronize()

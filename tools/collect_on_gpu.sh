@@ -10,14 +10,15 @@ R=$(pwd)
 mkdir -p "$D"
 D=$(cd "$D" && pwd)
 export TMPDIR=/tmp
+python3 -c "import sys; sys.path.insert(0, 'llm-quantization_amd'); from miq import _lib; print(_lib.source_digest())" > "$D/csrc.digest"
 echo "[collect] bench"; timeout -k 10 600 python3 -u bench.py > "$D/bench.json.log" 2> "$D/bench.err"
 cd /tmp
 echo "[collect] kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-block-calib > "$D/trace.log" 2>&1
 echo "[collect] pmc fetch"
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib > "$D/fetch.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib --no-families > "$D/fetch.log" 2>&1
 echo "[collect] pmc write"
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib > "$D/write.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib --no-families > "$D/write.log" 2>&1
 cd "$R"
 echo "[collect] families"; timeout -k 10 600 python3 -u tools/bench_families.py > "$D/families.json" 2> "$D/families.err"
 echo "[collect] blocks"
@@ -31,7 +32,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/bl
 echo "[collect] SQ counters (row quantizers, bench kernels)"
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 timeout -s KILL 120 rocprofv3 --pmc $SQ --output-format csv -d "$D/sq_rows" -- python3 "$R/tools/row_pmc.py" > "$D/sq_rows.log" 2>&1
-timeout -s KILL 120 rocprofv3 --pmc $SQ --output-format csv -d "$D/sq_bench" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib > "$D/sq_bench.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc $SQ --output-format csv -d "$D/sq_bench" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib --no-families > "$D/sq_bench.log" 2>&1
 cd "$R"
 python3 tools/row_pmc_summary.py "$D"/sq_rows/*/*counter_collection.csv "$D/sq_rows.json" > /dev/null
 python3 tools/row_pmc_summary.py "$D"/sq_bench/*/*counter_collection.csv "$D/sq_bench.json" > /dev/null

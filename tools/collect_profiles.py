@@ -57,8 +57,11 @@ def main():
     t["gather_fwd"] = t["gather_bwd"] = g
     t["_source"] = ("HBM bytes per bench step and kernel family = sum over the family's kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                     "from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --eager --steps 2 "
-                    f"--warmup 1 --no-cpu-baseline --no-block-calib` (profiles/{tag}_pmc_*.csv); bench.py divides by the family's "
+                    f"--warmup 1 --no-cpu-baseline --no-block-calib --no-families` (profiles/{tag}_pmc_*.csv); bench.py divides by the family's "
                     "launches per step")
+    dig = os.path.join(src, "csrc.digest")
+    if os.path.exists(dig):
+        t["_csrc_digest"] = open(dig).read().strip()
     json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
     print(json.dumps(t, indent=1))
 

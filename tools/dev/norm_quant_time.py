@@ -13,10 +13,15 @@ DEV = "cuda:0"
 
 
 def time_graph(fn, reps=9):
-    fn()
+    # warm up ON the capture stream: per-stream state of the library (the activation kernels' statistics table) must
+    # exist before the capture, which refuses to allocate it
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):
         fn()
     g.replay()
     torch.cuda.synchronize()
