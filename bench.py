@@ -7,7 +7,7 @@ One "step" = everything the quantizer kernels do for ONE calibration sample of 2
 (GEMMs / attention / layer norms are not part of this path and are not executed):
   forward   7 weight matrices row-wise W4 fake-quant with learnable clipping (fp32), batched per row width
             (6 matrices [*, 4096] in one launch, [4096, 11008] in another)
-            2 reorder gathers of the residual stream (fp16, [1,2048,4096])
+            2 reorder gathers of the residual stream (fp16, [1,2048,4096]), both in one launch
             10 activation sites: per-cluster EMA min/max calibration + A4 quantization; sites whose inputs exist side
             by side in a decoder block go through one call (the three q/k/v inputs, the three q/k/v projection
             outputs, the gate/up inputs: 5 calls of 2 launches for the 10 sites, forward and backward)
@@ -74,7 +74,7 @@ W_BITS, A_BITS = 4, 4
 SITE_GROUPS = [[0, 1, 2], [3, 4, 5], [6], [7, 8], [9]]
 # the rocprofv3 kernel behind every family (the activation families are chains; their streaming kernel is named)
 FAMILY_KERNEL = {"rowquant_fwd": "k_uniform_fwd_batch", "rowquant_bwd": "k_uniform_bwd_batch",
-                 "act_calib_quant_fwd": "k_colstat_slots + k_colquant_slots", "act_bwd": "k_colbwd_stream (+ k_colbwd_cluster)",
+                 "act_calib_quant_fwd": "k_colstat_slots + k_colquant_slots", "act_bwd": "k_colbwd_stream + k_colbwd_pairs",
                  "gather_fwd": "k_gather", "gather_bwd": "k_gather"}
 
 
@@ -145,7 +145,7 @@ class Workload:
     def launches(self):
         n_w = len({c for _n, _o, c in WEIGHTS})  # one launch per row width
         return {"rowquant_fwd": n_w, "rowquant_bwd": n_w, "act_calib_quant_fwd": 2 * len(SITE_GROUPS),
-                "act_bwd": 2 * len(SITE_GROUPS), "gather_fwd": 2, "gather_bwd": 2}
+                "act_bwd": 2 * len(SITE_GROUPS), "gather_fwd": 1, "gather_bwd": 1}
 
     def families(self):
         """Ordered (name, callable) pairs; every callable only enqueues kernels on the current stream."""
@@ -162,9 +162,8 @@ class Workload:
                 F.rowquant_uniform_fwd_batch([self.w[i] for i in ids], W_BITS, False, [self.up[i] for i in ids],
                                              [self.low[i] for i in ids])
 
-        def g_fwd():
-            for i in range(2):
-                F.gather_lastdim(self.res[i], self.idx[i])
+        def g_fwd():  # the inputs of the block's two reordered norms, one launch
+            F.gather_lastdim_batch(self.res, self.idx)
 
         x2 = [x.reshape(-1, x.shape[-1]) for x in self.x]
         g2 = [g.reshape(-1, g.shape[-1]) for g in self.gx]
@@ -180,8 +179,7 @@ class Workload:
                 F.act_fresh_quant_bwd([g2[i] for i in ids], [x2[i] for i in ids], vecs, A_BITS, self.layout[ids[0]])
 
         def g_bwd():
-            for i in range(2):
-                F.gather_lastdim(self.gres[i], self.inv[i])
+            F.gather_lastdim_batch(self.gres, self.inv)
 
         def w_bwd():
             grads.clear()

@@ -46,7 +46,7 @@ extern "C" {
  * raw factors and a flag bit 1 for this form; the bit is ignored now.) */
 
 /* major*10000 + minor*100 + patch of this interface; it grows when an entry point is added or a signature changes
- * (300: up / low are the activated clip factors in every row-wise entry point; 200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
+ * (301: miq_gather_lastdim_batch; 300: up / low are the activated clip factors in every row-wise entry point; 200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
  * miq_act_quant_from_table, miq_gather_layernorm_bwd, miq_act_calib_quant_fwd_static) */
 int miq_version(void);
 const char* miq_last_error(void);
@@ -242,6 +242,11 @@ int miq_act_calib_quant_fwd_static(const void* x, const void* cached_min, const 
  */
 int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int64_t C, int dtype,
                        void* stream);
+/* The same for up to 8 tensors of one shape and dtype in one launch, each with its own index (x, idx, out: HOST arrays
+ * of n device pointers): the two reordered layer norms of a block gather tensors of one shape
+ * (R1 / R4 of quantize/reorder_utils.py:6-58), and a 16.8 MB gather alone is bound by the launch, not by memory. */
+int miq_gather_lastdim_batch(int n, const void* const* x, const int* const* idx, void* const* out, int64_t R, int64_t C,
+                             int dtype, void* stream);
 
 /*
  * RPTQ reorder gather fused into LayerNorm, forward (OmniLayerNorm.forward with a reorder index,

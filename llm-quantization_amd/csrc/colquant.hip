@@ -9,7 +9,6 @@
 // Semantics: UniformAffineQuantizer.per_cluster_minmax_calibration / per_tensor_minmax_calibration /
 // calibration / fake_quant (reference quantize/quantizer.py:157-238,99-121) and the index_select in
 // OmniLayerNorm.forward (quantize/omni_norm.py:36-40).
-#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include "miq_common.h"
@@ -516,11 +515,21 @@ k_colquant_slots(SlabPtrs xs, SlotMap sm, u64* ws_base, long long ws_stride, Sla
 // channel gather out[r, c] = x[r, idx[c]]: rows are staged in LDS with coalesced 16-byte loads and
 // read back through the index, stores are coalesced again.
 // ---------------------------------------------------------------------------------------------
+// up to kMaxSlabs tensors of one shape per launch (blockIdx.y), each with its own index
+struct GatherSlabs {
+    const void* x[kMaxSlabs];
+    const int* idx[kMaxSlabs];
+    void* out[kMaxSlabs];
+};
+
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-k_gather(const T* __restrict__ x, const int* __restrict__ idx, T* __restrict__ out, long long R, int C, int rows_per_block) {
+k_gather(GatherSlabs slabs, long long R, int C, int rows_per_block) {
     extern __shared__ __align__(16) unsigned char smem[];
     T* tile = reinterpret_cast<T*>(smem);  // [rows_per_block][C]
+    const T* __restrict__ x = static_cast<const T*>(slabs.x[blockIdx.y]);
+    const int* __restrict__ idx = slabs.idx[blockIdx.y];
+    T* __restrict__ out = static_cast<T*>(slabs.out[blockIdx.y]);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     int nr = rows_per_block;
     if (r0 + nr > R) nr = (int)(R - r0);
@@ -600,26 +609,35 @@ static int launch_colquant_fwd(const void* x, const void* scale, const void* rzp
 }
 
 template <typename T>
-static int launch_gather(const void* x, const int* idx, void* out, long long R, long long C, hipStream_t stream) {
+static int launch_gather(int n, const void* const* x, const int* const* idx, void* const* out, long long R, long long C,
+                         hipStream_t stream) {
     constexpr int N = VecOf<T>::N;
-    const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(out);
+    GatherSlabs slabs{};
+    bool vec_ok = (C % N == 0);
+    for (int i = 0; i < n; ++i) {
+        MIQ_CHECK_ARG(x[i] && idx[i] && out[i], "miq_gather_lastdim: null pointer in tensor %d", i);
+        slabs.x[i] = x[i];
+        slabs.idx[i] = idx[i];
+        slabs.out[i] = out[i];
+        vec_ok = vec_ok && aligned16(x[i]) && aligned16(out[i]);
+    }
     const long long row_bytes = C * (long long)sizeof(T);
     MIQ_CHECK_ARG(row_bytes <= 160 * 1024, "miq_gather_lastdim: a row of %lld bytes does not fit in LDS", row_bytes);
     int rows = (int)(65536 / row_bytes);
     if (rows < 1) rows = 1;
     if (rows > 16) rows = 16;
-    // at least ~1024 blocks when the slab has that many rows: several small tiles per CU stream better than one big one
-    const long long want_rows = R / 1024;
+    // at least ~1024 blocks when the tensors have that many rows: several small tiles per CU stream better than one big one
+    const long long want_rows = R * n / 1024;
     if (rows > want_rows) rows = (int)(want_rows < 1 ? 1 : want_rows);
     if (rows > R) rows = (int)R;
     const size_t lds = (size_t)rows * row_bytes;
-    const unsigned grid = (unsigned)((R + rows - 1) / rows);
+    const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)n);
     if (vec_ok) {
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_gather<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gather<T, N>), dim3(grid), dim3(256), lds, stream, (const T*)x, idx, (T*)out, R, (int)C, rows);
+        hipLaunchKernelGGL((k_gather<T, N>), grid, dim3(256), lds, stream, slabs, R, (int)C, rows);
     } else {
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_gather<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gather<T, 1>), dim3(grid), dim3(256), lds, stream, (const T*)x, idx, (T*)out, R, (int)C, rows);
+        hipLaunchKernelGGL((k_gather<T, 1>), grid, dim3(256), lds, stream, slabs, R, (int)C, rows);
     }
     MIQ_CHECK_LAUNCH("miq_gather_lastdim");
     return 0;
@@ -785,21 +803,7 @@ static int act_fresh_t(int n, const void* const* x, int64_t cluster_size, const 
     if (vec_ok) {
         // fp32 keeps 8 rows per lane in flight, fp16 (twice the channels per pack, twice the conversions) 4
         constexpr int D = sizeof(T) == 4 ? 8 : 4;
-        // development knobs (tools/dev): rows per block and loads in flight of the statistics kernel alone; the slot table
-        // makes its grid independent of the quantize kernel's
-        static const int knob_rows = getenv("MIQ_STAT_ROWS") ? atoi(getenv("MIQ_STAT_ROWS")) : 0;
-        static const int knob_depth = getenv("MIQ_STAT_DEPTH") ? atoi(getenv("MIQ_STAT_DEPTH")) : 0;
-        if (uniform && (knob_rows > 0 || knob_depth > 0)) {
-            const int rpc_s = knob_rows > 0 ? knob_rows : rpc;
-            const int nchunk_s = (int)((R + rpc_s - 1) / rpc_s);
-            const int nrep_s = nchunk_s > 16 ? kSlotReplicas : 1;
-            MIQ_CHECK_ARG(nrep_s == nrep, "MIQ_STAT_ROWS: the two kernels must agree on the replica count");
-            const dim3 grid_s(tiles, nchunk_s, n);
-            if ((knob_depth > 0 ? knob_depth : D) == 8)
-                hipLaunchKernelGGL((k_colstat_slots<T, N, 8, true>), grid_s, dim3(256), 0, stream, xs, R, (int)C, rpc_s, sm, ws, ws_stride, nrep);
-            else
-                hipLaunchKernelGGL((k_colstat_slots<T, N, 4, true>), grid_s, dim3(256), 0, stream, xs, R, (int)C, rpc_s, sm, ws, ws_stride, nrep);
-        } else if (uniform) hipLaunchKernelGGL((k_colstat_slots<T, N, D, true>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
+        if (uniform) hipLaunchKernelGGL((k_colstat_slots<T, N, D, true>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
         else hipLaunchKernelGGL((k_colstat_slots<T, N, D, false>), grid, dim3(256), 0, stream, xs, R, (int)C, rpc, sm, ws, ws_stride, nrep);
         if (nrep == 1) launch_fresh_quant<T, N, 1>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
         else launch_fresh_quant<T, N, kSlotReplicas>(uniform, grid, stream, xs, sm, ws, ws_stride, outs, codes, vecs, R, (int)C, rpc, qmax);
@@ -949,11 +953,19 @@ extern "C" int miq_act_calib_quant_fwd_static(const void* x, const void* cached_
     return 0;
 }
 
+extern "C" int miq_gather_lastdim_batch(int n, const void* const* x, const int* const* idx, void* const* out, int64_t R, int64_t C,
+                                        int dtype, void* stream) {
+    if (n == 0 || R == 0 || C == 0) return 0;
+    MIQ_CHECK_ARG(n > 0 && n <= kMaxSlabs, "miq_gather_lastdim_batch: %d tensors (1..%d per call)", n, kMaxSlabs);
+    MIQ_CHECK_ARG(x && idx && out && R > 0 && C > 0 && C < (1ll << 31), "miq_gather_lastdim_batch: null pointer or bad shape");
+    if (dtype == MIQ_F32) return launch_gather<float>(n, x, idx, out, R, C, (hipStream_t)stream);
+    if (dtype == MIQ_F16) return launch_gather<__half>(n, x, idx, out, R, C, (hipStream_t)stream);
+    miq_set_error("miq_gather_lastdim_batch: unsupported dtype %d", dtype);
+    return -22;
+}
+
 extern "C" int miq_gather_lastdim(const void* x, const int* idx, void* out, int64_t R, int64_t C, int dtype, void* stream) {
     if (R == 0 || C == 0) return 0;
     MIQ_CHECK_ARG(x && idx && out && R > 0 && C > 0 && C < (1ll << 31), "miq_gather_lastdim: null pointer or bad shape");
-    if (dtype == MIQ_F32) return launch_gather<float>(x, idx, out, R, C, (hipStream_t)stream);
-    if (dtype == MIQ_F16) return launch_gather<__half>(x, idx, out, R, C, (hipStream_t)stream);
-    miq_set_error("miq_gather_lastdim: unsupported dtype %d", dtype);
-    return -22;
+    return miq_gather_lastdim_batch(1, &x, &idx, &out, R, C, dtype, stream);
 }

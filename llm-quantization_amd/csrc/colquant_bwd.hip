@@ -119,7 +119,9 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
     // flight (a chunk is typically 32 rows: one or two batches per wave).  The first batch is issued before the per-channel parameters are fetched.
     // 32 elements per batch keep the kernel under 128 registers (four waves per SIMD) without spills; larger
     // batches were measured: no faster in fp32, slower in fp16
-    constexpr int UNR = VEC == 8 ? 2 : 4;  // (fp16 with 4 rows, retried with the one-parameter-set form: 64 bytes of spills, 3 % slower)
+    // (fp16 with 4 rows: 64 bytes of spills and 3 % slower in the per-channel form; in the per-lane form, which holds no
+    // tie counters, 128 registers without spills and 5-10 % slower)
+    constexpr int UNR = VEC == 8 ? 2 : 4;
     // fp16 (two rows per batch: half the bytes in flight of the fp32 form) requests the next batch before it works on
     // the current one
     constexpr bool PREFETCH = VEC == 8;
@@ -989,10 +991,13 @@ extern "C" int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const
         slabs.s[i] = BwdSlab{x[i], grad_out[i], v + 2 * C * es, v + 4 * C * es, v, v + C * es, nullptr, nullptr, dx[i],
                              static_cast<float*>(workspace) + i * stride};
     }
-    const int nchunk = miq_colstat_chunks(R, C, dtype);
+    int nchunk = miq_colstat_chunks(R, C, dtype);
     const bool merged = cluster_size > 0 && cluster_size <= kClusterMax && covered == C;
     // every 16-byte pack of channels inside one cluster: one parameter set per lane in the streaming kernel
     const bool uniform = cluster_size > 0 && covered == C && cluster_size % (dtype == MIQ_F16 ? 8 : 4) == 0;
+    // The per-lane partials are so small that the row chunks can shrink: fp32 slabs stream 5 % faster in twice the
+    // blocks (16-row chunks: one four-row batch per wave), fp16 slabs 8 % slower (measured on the Llama-2-7B sites)
+    if (merged && uniform && dtype == MIQ_F32 && (R + 2 * nchunk - 1) / (2 * nchunk) >= 16) nchunk *= 2;
     if (dtype == MIQ_F32)
         return colquant_bwd_launch<float>(slabs, n, true, starts, n_clusters, covered, nchunk, R, C, n_bits, 0, merged, uniform,
                                           flat_ties ? 1 : 0, (hipStream_t)stream, "miq_act_fresh_quant_bwd");

@@ -479,6 +479,9 @@ __device__ __forceinline__ int batch_locate(const UniBatch<T>& b, long long row,
 // ---------------------------------------------------------------------------------------------
 // 11008-wide fp32 rows (2752 packs) take a 6-pack tile on 512 lanes: the 8-pack tile's registers for packs that hold
 // nothing cost the forward kernels 2-3 % (and the LET forward, which keeps three vectors per pack, a third of its time).
+// Likewise 5120-wide rows (Llama-2-13B: 1280 packs = 256 x 5 exactly), 13824-wide (3456 packs: 512 x 7) and
+// 28672-wide (Llama-2-70B: 7168 packs = 1024 x 7 exactly): a pack a lane never loads still costs the backward kernels
+// two register quads, and with them a wave per SIMD.
 // Teams that are not powers of two (384 x 8 for 11008-wide rows, 320 x 4, 448 x 8, 896 x 8) remove the idle
 // lanes of the next larger tile but were measured slower in the backward kernels (6 or 7 waves per block
 // spread unevenly over the 4 SIMDs), so the table stays with power-of-two teams.
@@ -499,9 +502,12 @@ __device__ __forceinline__ int batch_locate(const UniBatch<T>& b, long long row,
             else { LAUNCH(1024, 8); }                                    \
         } else {                                                         \
             if ((NPACK) <= 1024) { LAUNCH(256, 4); }                     \
+            else if ((NPACK) <= 1280) { LAUNCH(256, 5); }                \
             else if ((NPACK) <= 2048) { LAUNCH(256, 8); }                \
             else if ((NPACK) <= 3072) { LAUNCH(512, 6); }                \
+            else if ((NPACK) <= 3584) { LAUNCH(512, 7); }                \
             else if ((NPACK) <= 4096) { LAUNCH(512, 8); }                \
+            else if ((NPACK) <= 7168) { LAUNCH(1024, 7); }               \
             else { LAUNCH(1024, 8); }                                    \
         }                                                                \
     } while (0)
@@ -527,9 +533,12 @@ __device__ __forceinline__ int batch_locate(const UniBatch<T>& b, long long row,
             else MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 8, GEO, STREAM, __VA_ARGS__)                      \
         } else {                                                                                           \
             if ((NPACK) <= 1024) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 4, GEO, STREAM, __VA_ARGS__)       \
+            else if ((NPACK) <= 1280) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 5, GEO, STREAM, __VA_ARGS__)  \
             else if ((NPACK) <= 2048) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 256, 8, GEO, STREAM, __VA_ARGS__)  \
             else if ((NPACK) <= 3072) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 6, GEO, STREAM, __VA_ARGS__)  \
+            else if ((NPACK) <= 3584) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 7, GEO, STREAM, __VA_ARGS__)  \
             else if ((NPACK) <= 4096) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 512, 8, GEO, STREAM, __VA_ARGS__)  \
+            else if ((NPACK) <= 7168) MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 7, GEO, STREAM, __VA_ARGS__) \
             else MIQ_ROW_LAUNCH_ONE(KERN, T, VECN, 1024, 8, GEO, STREAM, __VA_ARGS__)                      \
         }                                                                                                  \
     } while (0)

@@ -76,42 +76,68 @@ __device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c, const 
 }
 
 // fp32 rows in which every quotient is finite (finite extremes, a scale that is not NaN, |x / s| far below the range
-// where the residual of the corrected product could overflow): the element function without the NaN-preserving forms.
-// Same bits as exp2_elem there: the clamps are medians / minima of finite values, 2^t needs no NaN test, and the sign
-// is copied from q + 0 (sgnf gives 0 for a quotient of either zero, and the level of a zero quotient is 0 already).
+// where the residual of the corrected product could overflow) take element functions without the NaN-preserving forms
+// and without the logarithm.
+//
+// The reference picks the level 2^round(log2(a / 1.5) + 0.5) of a magnitude a = |x / s| >= 0.5.  With y = RN(a / 1.5) that
+// is the smallest power of two >= y, and for y an exact power of two 2^j the tie of round-half-to-even: 2^(j + (j & 1)).
+// RN(a / 1.5) is monotone in a and crosses 2^j exactly at a = 1.5 * 2^j (the neighbouring floats of 1.5 * 2^j map below
+// and above 2^j), so the level is a function of comparisons of a itself:
+//   a < 0.5 -> 0 | a <= 1.5 -> 1 | a < 3 -> 2 | a <= 6 -> 4 | a < 12 -> 8 | a <= 24 -> 16 | ...
+// In the reference's float arithmetic t = fl(fl(log2 y) + 0.5) the addition rounds too, which moves each threshold by a
+// few ulp: with a correctly rounded log2 the float just below 3 already gives t = 1.5 and level 4, while 1.5 and 6 stay
+// on the lower level.  Up to 3 bits (levels 0, 1, 2, 4, and "beyond the top") three or four compare-and-selects against
+// those exact floats replace divide, log2, round, ldexp.  From 4 bits on the exponent field of y decides; there an
+// element within 5 ulp of a threshold may land on the neighbouring level (the stated tolerance of the exponent grids,
+// the same the logarithm instruction has).
 __device__ __forceinline__ bool exp2_plain_row(const Exp2Ctx& c, float rmin, float rmax) {
     const float bound = __builtin_fmaxf(fabsf(rmin), fabsf(rmax)) / c.s;
     return (rmin == rmin) && (rmax == rmax) && (bound <= 0x1p60f);  // a NaN scale gives a NaN bound
 }
+// unclamped level of a magnitude a0 >= 0.5 (anything for smaller ones: the caller zeroes them)
+template <bool SMALL>
+__device__ __forceinline__ float exp2_level_of(float a0) {
+    if constexpr (SMALL) {  // n_bits <= 3: top <= 4; 8 stands for every level beyond it
+        return a0 <= 1.5f ? 1.f : (a0 < 0x1.7ffffep+1f ? 2.f : (a0 <= 6.f ? 4.f : 8.f));  // 0x1.7ffffep+1: the float below 3
+    } else {
+        const unsigned b = __float_as_uint(div_1p5(__builtin_amdgcn_fmed3f(a0, 1e-4f, 1e4f)));  // y > 0
+        const int eb = (int)(b >> 23);                                    // biased exponent
+        const int inc = (b & 0x7FFFFFu) ? 1 : ((eb & 1) ^ 1);            // above 2^j: next power; at 2^j: j + (j & 1), j = eb - 127
+        int kb = eb + inc;
+        kb = kb < 127 ? 127 : kb;                                         // y < 0.5 (t < -0.5 in the reference): level 2^0
+        return __uint_as_float((unsigned)kb << 23);
+    }
+}
+template <bool SMALL>
 __device__ __forceinline__ float exp2_plain_level(float xv, const Exp2Ctx& c, float rs) {
     const float q0 = xv * rs;
     const float q = __builtin_fmaf(__builtin_fmaf(-q0, c.s, xv), rs, q0);  // the IEEE quotient for 2^-80 <= |q0|; below it
     const float a0 = fabsf(q);                                             // the level is 0 whichever way it rounds
-    const float mag = __builtin_amdgcn_fmed3f(a0, 1e-4f, 1e4f);
-    float t = __log2f(div_1p5(mag)) + 0.5f;
-    if (t < -0.5f) t = 0.f;
-    float e = ldexpf(1.0f, (int)rintf(t));
+    float e = exp2_level_of<SMALL>(a0);
     if (a0 < 0.5f) e = 0.f;
     return __builtin_copysignf(__builtin_fminf(e, c.top), q + 0.f);
 }
 
-// the element record of the backward for such a row (fields as exp2_elem fills them)
-__device__ __forceinline__ Exp2Elem exp2_plain_elem(float xv, const Exp2Ctx& c, float rs) {
-    Exp2Elem r;
+// The backward of such a row whose magnitudes also stay below the reference's clamp at 1e4.  An element is ALIVE when its
+// level is neither the zero bin (a < 0.5), nor taken from the threshold branch (t < -0.5: a < 0.75), nor beyond the top.
+// For an alive element the reference's chain gives grad_q = g * s * lvl / a and dx = grad_q / s = g * lvl / a, and its
+// two contributions to the scale gradient, g * lvl * sign and grad_q * (-x / s^2) = -g * lvl * sign, cancel: only
+// elements that are not alive contribute g * clamp(lvl) * sign (zero for the zero bin).  dx: the gradient w.r.t. x;
+// ds: the element's term of the scale gradient.
+template <bool SMALL>
+__device__ __forceinline__ void exp2_plain_grad(float xv, float gv, const Exp2Ctx& c, float rs, float& dx, float& ds) {
     const float q0 = xv * rs;
     const float q = __builtin_fmaf(__builtin_fmaf(-q0, c.s, xv), rs, q0);
     const float a0 = fabsf(q);
-    r.sign = 0.f;  // not used by the plain form of the gradient (see grad_q)
-    r.is_zero = a0 < 0.5f;
-    r.mag = __builtin_amdgcn_fmed3f(a0, 1e-4f, 1e4f);
-    float t = __log2f(div_1p5(r.mag)) + 0.5f;
-    r.below = t < -0.5f;
-    if (r.below) t = 0.f;
-    float e = ldexpf(1.0f, (int)rintf(t));
-    if (r.is_zero) e = 0.f;
-    r.lvl = e;
-    r.signed_lvl = __builtin_copysignf(__builtin_fminf(e, c.top), q + 0.f);
-    return r;
+    const float lvl = exp2_level_of<SMALL>(a0);
+    const bool alive = (a0 >= 0.75f) & (lvl <= c.top);
+    const float sat = a0 < 0.5f ? 0.f : __builtin_fminf(lvl, c.top);
+    dx = alive ? (gv * lvl) * __builtin_amdgcn_rcpf(a0) : 0.f;
+    ds = alive ? 0.f : gv * __builtin_copysignf(sat, q + 0.f);
+}
+__device__ __forceinline__ bool exp2_plain_grad_row(const Exp2Ctx& c, float rmin, float rmax) {
+    const float bound = __builtin_fmaxf(fabsf(rmin), fabsf(rmax)) / c.s;
+    return (rmin == rmin) && (rmax == rmax) && (bound <= 1e4f);
 }
 
 // the work of one team on one quantization row
@@ -131,14 +157,19 @@ __device__ __forceinline__ void exp2_fwd_row(const ExpArgs<T>& a, const RowGeom&
     if constexpr (sizeof(T) == 4) {
         if (exp2_plain_row(c, rmin, rmax)) {  // a property of the row: tested once, not per element
             const float rs = 1.0f / c.s;
+            auto plain_row = [&](auto small_tag) {
+                constexpr bool SMALL = decltype(small_tag)::value;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                if (!x.has(k)) continue;
-                Pack<T, VEC> o;
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+                    Pack<T, VEC> o;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_plain_level(to_f<T>(x.v[k].e[e]), c, rs) * c.s);
-                st_pack<T, VEC>(out + base + x.offset(k), o);
-            }
+                    for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_plain_level<SMALL>(to_f<T>(x.v[k].e[e]), c, rs) * c.s);
+                    st_pack<T, VEC>(out + base + x.offset(k), o);
+                }
+            };
+            if (a.n_bits <= 3) plain_row(std::true_type{});
+            else plain_row(std::false_type{});
             return;
         }
     }
@@ -206,18 +237,14 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
     const typename BwdDivisorOf<T>::type dv(c.s);
     const float hi_dead = rnd<T>(c.top + 0.0001f), lo_dead = rnd<T>(-c.top + 0.0001f);
-    // PLAIN (a row of finite quotients): the sign is +-1 wherever the gradient is not dead, and it enters twice (the
-    // negation of gq and the final factor): the two cancel exactly, so neither is applied
-    auto grad_q = [&](float gv, const Exp2Elem& el, auto plain_tag) {
-        constexpr bool PLAIN_SIGN = decltype(plain_tag)::value;
+    auto grad_q = [&](float gv, const Exp2Elem& el) {
         float gq = gv * c.s;
-        if (!PLAIN_SIGN && el.sign == -1.f) gq = -gq;
+        if (el.sign == -1.f) gq = -gq;
         // the comparison constants are rounded to the tensor dtype, as the reference's `q_exp.ge(qmax+0.0001)` does
         // (bitwise | and a select: with || and an early return the compiler branches around the product for every element)
         const bool dead = (el.lvl >= hi_dead) | (el.lvl <= lo_dead) | el.is_zero | el.below;
         // gradients are tolerance-checked sums: the hardware reciprocal (1 ulp) instead of an IEEE division (__frcp_rn is one)
-        float v = ((kLn2 * el.lvl) * gq) * kInvLn2 * __builtin_amdgcn_rcpf(el.mag);
-        if (!PLAIN_SIGN) v *= el.sign;
+        const float v = ((kLn2 * el.lvl) * gq) * kInvLn2 * __builtin_amdgcn_rcpf(el.mag) * el.sign;
         return dead ? 0.f : v;
     };
     const float inv_s = 1.0f / c.s, neg_inv_s2 = -1.0f / (c.s * c.s);
@@ -227,18 +254,15 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     constexpr bool kSide = !kInPlace && NV * VEC <= 32;
     float side[kSide ? NV * VEC : 1];
     float acc[3] = {0.f, 0.f, 0.f};
-    auto row_sums = [&](auto plain_tag) {
-        constexpr bool PLAIN = decltype(plain_tag)::value;
+    auto row_sums = [&]() {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-                Exp2Elem el;
-                if constexpr (PLAIN) el = exp2_plain_elem(xv, c, inv_s);
-                else el = exp2_elem<T>(xv, c, dv);
-                const float gqq = grad_q(gv, el, plain_tag);
+                const Exp2Elem el = exp2_elem<T>(xv, c, dv);
+                const float gqq = grad_q(gv, el);
                 if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(gqq);
                 if constexpr (kSide) side[k * VEC + e] = gqq;
                 acc[0] += gv * el.signed_lvl + gqq * (xv * neg_inv_s2);
@@ -249,11 +273,32 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
             }
         }
     };
+    // fp32 rows of ordinary values: the closed form per element (g's registers then hold dx itself, not grad_q)
+    float post = inv_s;
     if constexpr (sizeof(T) == 4) {
-        if (exp2_plain_row(c, rmin, rmax)) row_sums(std::true_type{});  // a property of the row, tested once
-        else row_sums(std::false_type{});
+        if (exp2_plain_grad_row(c, rmin, rmax)) {  // a property of the row, tested once
+            auto plain_sums = [&](auto small_tag) {
+                constexpr bool SMALL = decltype(small_tag)::value;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float d, ds;
+                        exp2_plain_grad<SMALL>(to_f<T>(x.v[k].e[e]), to_f<T>(g.v[k].e[e]), c, inv_s, d, ds);
+                        g.v[k].e[e] = from_f<T>(d);
+                        acc[0] += ds;
+                    }
+                }
+            };
+            if (a.n_bits <= 3) plain_sums(std::true_type{});
+            else plain_sums(std::false_type{});
+            post = 1.f;
+        } else {
+            row_sums();
+        }
     } else {
-        row_sums(std::false_type{});
+        row_sums();
     }
     if constexpr (kLaneTies) {
         if (at_extreme) {
@@ -284,18 +329,18 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const float xv = to_f<T>(x.v[k].e[e]);
-                        float d = to_f<T>(g.v[k].e[e]) * inv_s;
+                        float d = to_f<T>(g.v[k].e[e]) * post;
                         if (xv == rmax) d += share_max;
                         if (xv == rmin) d += share_min;
                         g.v[k].e[e] = from_f<T>(d);
                     }
                 }
-            } else {
+            } else if (post != 1.f) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     if (!x.has(k)) continue;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) g.v[k].e[e] = from_f<T>(to_f<T>(g.v[k].e[e]) * inv_s);
+                    for (int e = 0; e < VEC; ++e) g.v[k].e[e] = from_f<T>(to_f<T>(g.v[k].e[e]) * post);
                 }
             }
 #pragma unroll
@@ -319,7 +364,7 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
                 float gqq;
                 if constexpr (kInPlace) gqq = gv;  // overwritten above
                 else if constexpr (kSide) gqq = side[k * VEC + e];
-                else gqq = grad_q(gv, exp2_elem<T>(xv, c, dv), std::false_type{});
+                else gqq = grad_q(gv, exp2_elem<T>(xv, c, dv));
                 float d = gqq * inv_s;
                 if (xv == rmax) d += share_max;
                 if (xv == rmin) d += share_min;
@@ -361,7 +406,7 @@ k_exp2_bwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
 // ------------------------------------------------------------------------------------------ v1
 struct Exp1Ctx {
     ClipCtx clip;
-    float s, s_raw, mid, e_lo;
+    float s, s_raw, mid, e_lo, p_lo;  // p_lo = 2^e_lo, the smallest level
     bool has_mid;
 };
 
@@ -370,6 +415,7 @@ __device__ __forceinline__ Exp1Ctx exp1_ctx(const ExpArgs<T>& a, long long row, 
     Exp1Ctx c;
     c.clip = lwc_clip<T>(a.up, a.low, row, rmin, rmax);
     c.e_lo = -(float)((1 << (a.n_bits - 1)) - 1);
+    c.p_lo = ldexpf(1.0f, -((1 << (a.n_bits - 1)) - 1));
     const float lo = rnd<T>(kClipLo);
     if (a.symmetric) {
         c.s_raw = nmax(fabsf(c.clip.xmax), fabsf(c.clip.xmin));
@@ -415,17 +461,52 @@ __device__ __forceinline__ bool exp1_plain_row(const Exp1Ctx& c, float rmin, flo
     const float bound = 2.f * __builtin_fmaxf(fabsf(rmin), fabsf(rmax)) / c.s;
     return (rmin == rmin) && (rmax == rmax) && (bound <= 0x1p60f) && (fabsf(c.mid) <= 0x1p100f);
 }
+// The level 2^clamp(round(log2 a), e_lo, 0) of a magnitude a without the logarithm: round(log2 a) = k exactly when
+// 2^(k - 0.5) < a < 2^(k + 0.5).  The thresholds are irrational, so which of the two floats around one is the first of
+// the upper level is decided by the last bit of fl(log2 a); kExp1From[j] is the first float that a correctly rounded
+// log2 sends to level 2^-j.  Up to 3 bits (levels 1, 1/2, 1/4, 1/8) three compare-and-selects against those floats; from
+// 4 bits on the exponent field and a comparison of the significand with sqrt(2), where an element within a few ulp of
+// a threshold may land on the neighbouring level (the stated tolerance of the exponent grids).
+__device__ constexpr float kExp1From[4] = {0x1.6a09e6p-1f, 0x1.6a09e8p-2f, 0x1.6a09e6p-3f, 0x1.6a09eap-4f};
+constexpr float kExp1Above = 0x1.6a09e8p+0f;  // the first float whose log2 rounds to 1
+template <bool SMALL>
+__device__ __forceinline__ float exp1_level_of(float a, const Exp1Ctx& c) {
+    if constexpr (SMALL) {
+        const float p = a >= 0x1.6a09e6p-1f ? 1.f : (a >= 0x1.6a09e8p-2f ? 0.5f : (a >= 0x1.6a09e6p-3f ? 0.25f : 0.125f));
+        return __builtin_fmaxf(p, c.p_lo);
+    } else {
+        const unsigned b = __float_as_uint(a);  // a in [1e-5, 1e4]
+        int k = (int)(b >> 23) - 127 + ((b & 0x7FFFFFu) > 0x3504F3u ? 1 : 0);
+        const int lo = (int)c.e_lo;
+        k = k < lo ? lo : (k > 0 ? 0 : k);
+        return __uint_as_float((unsigned)(k + 127) << 23);
+    }
+}
+template <bool SMALL>
 __device__ __forceinline__ float exp1_plain_out(float xv, const Exp1Ctx& c, float rs) {
     const float v = c.has_mid ? xv - c.mid : xv;
     const float q0 = v * rs;
     const float u = __builtin_fmaf(__builtin_fmaf(-q0, c.s, v), rs, q0);  // below 2^-80 the magnitude clamps to 1e-5 either way
-    const float mag = __builtin_amdgcn_fmed3f(fabsf(u), kClipLo, kClipHi);
-    const float l = __log2f(mag);
-    const float lround = (rintf(l) - l) + l;
-    const float p = ldexpf(1.0f, (int)__builtin_amdgcn_fmed3f(lround, c.e_lo, 0.f));
+    const float p = exp1_level_of<SMALL>(__builtin_amdgcn_fmed3f(fabsf(u), kClipLo, kClipHi), c);
     const float ps = (v != 0.f) ? __builtin_copysignf(p, v) : 0.f;
     const float o = ps * c.s;
     return c.has_mid ? o + c.mid : o;
+}
+// The backward of such a row.  An element is LIVE when round(log2 |u|) lies in [e_lo, 0] and |u| in [1e-5, 1e4]:
+// 2^(e_lo - 0.5) < |u| < 2^0.5 (the clamp bounds lie outside that interval).  For a live element autograd's chain
+// through pow, round_ste, log2, clamp and abs gives du = g * s * p / |u|, so dv = du / s = g * p / |u|, and its two
+// contributions to the scale gradient, g * p * sign and du * (-v / s^2) = -g * p * sign, cancel; an element that is not
+// live contributes g * p * sign (p: the clamped level) and has dv = 0.  The midpoint gradient collects g - dv.
+template <bool SMALL>
+__device__ __forceinline__ void exp1_plain_grad(float xv, float gv, const Exp1Ctx& c, float rs, float t_lo, float& dv, float& ds) {
+    const float v = c.has_mid ? xv - c.mid : xv;
+    const float q0 = v * rs;
+    const float u = __builtin_fmaf(__builtin_fmaf(-q0, c.s, v), rs, q0);
+    const float a = fabsf(u);
+    const float p = exp1_level_of<SMALL>(__builtin_amdgcn_fmed3f(a, kClipLo, kClipHi), c);
+    const bool live = (a >= t_lo) & (a < kExp1Above);
+    dv = live ? (gv * p) * __builtin_amdgcn_rcpf(a) : 0.f;
+    ds = (live | (v == 0.f)) ? 0.f : gv * __builtin_copysignf(p, v);
 }
 
 template <typename T, int VEC, int TEAM, int NV>
@@ -452,14 +533,19 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     if constexpr (sizeof(T) == 4) {
         if (exp1_plain_row(c, rmin, rmax)) {  // a property of the row: tested once, not per element
             const float rs = 1.0f / c.s;
+            auto plain_row = [&](auto small_tag) {
+                constexpr bool SMALL = decltype(small_tag)::value;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                if (!x.has(k)) continue;
-                Pack<T, VEC> o;
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+                    Pack<T, VEC> o;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_plain_out(to_f<T>(x.v[k].e[e]), c, rs));
-                st_pack<T, VEC>(out + base + x.offset(k), o);
-            }
+                    for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_plain_out<SMALL>(to_f<T>(x.v[k].e[e]), c, rs));
+                    st_pack<T, VEC>(out + base + x.offset(k), o);
+                }
+            };
+            if (a.n_bits <= 3) plain_row(std::true_type{});
+            else plain_row(std::false_type{});
             return;
         }
     }
@@ -513,23 +599,56 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     constexpr bool kSide = !kInPlace && NV * VEC <= 32;
     float side[kSide ? NV * VEC : 1];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};  // d_s, d_mid, #max, #min
+    auto row_sums = [&]() {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
-            const Exp1Elem el = exp1_elem<T>(xv, c, dv);
-            const float du = d_u(gv, el);
-            if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(du);
-            if constexpr (kSide) side[k * VEC + e] = du;
-            acc[0] += gv * (el.p * el.sign) + du * (el.v * neg_inv_s2);
-            acc[1] += gv - du * inv_s;
-            if constexpr (!kLaneTies) {
-                acc[2] += (xv == rmax) ? 1.f : 0.f;
-                acc[3] += (xv == rmin) ? 1.f : 0.f;
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = to_f<T>(x.v[k].e[e]), gv = to_f<T>(g.v[k].e[e]);
+                const Exp1Elem el = exp1_elem<T>(xv, c, dv);
+                const float du = d_u(gv, el);
+                if constexpr (kInPlace) g.v[k].e[e] = from_f<T>(du);
+                if constexpr (kSide) side[k * VEC + e] = du;
+                acc[0] += gv * (el.p * el.sign) + du * (el.v * neg_inv_s2);
+                acc[1] += gv - du * inv_s;
+                if constexpr (!kLaneTies) {
+                    acc[2] += (xv == rmax) ? 1.f : 0.f;
+                    acc[3] += (xv == rmin) ? 1.f : 0.f;
+                }
             }
         }
+    };
+    // fp32 rows of ordinary values: the closed form per element (g's registers then hold dx itself)
+    float post = inv_s;
+    if constexpr (sizeof(T) == 4) {
+        if (exp1_plain_row(c, rmin, rmax)) {  // a property of the row, tested once
+            // the first float of the lowest level e_lo = -(2^(n_bits - 1) - 1): exact up to 3 bits, next(2^(e_lo - 0.5)) beyond
+            const float t_lo = a.n_bits <= 3 ? kExp1From[(1 << (a.n_bits - 1)) - 1] : __uint_as_float(__float_as_uint(c.p_lo * 0x1.6a09e6p-1f) + 1u);
+            auto plain_sums = [&](auto small_tag) {
+                constexpr bool SMALL = decltype(small_tag)::value;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (!x.has(k)) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float gv = to_f<T>(g.v[k].e[e]);
+                        float d, ds;
+                        exp1_plain_grad<SMALL>(to_f<T>(x.v[k].e[e]), gv, c, inv_s, t_lo, d, ds);
+                        g.v[k].e[e] = from_f<T>(d);
+                        acc[0] += ds;
+                        acc[1] += gv - d;
+                    }
+                }
+            };
+            if (a.n_bits <= 3) plain_sums(std::true_type{});
+            else plain_sums(std::false_type{});
+            post = 1.f;
+        } else {
+            row_sums();
+        }
+    } else {
+        row_sums();
     }
     if constexpr (kLaneTies) {
         if (at_extreme) {
@@ -566,18 +685,18 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const float xv = to_f<T>(x.v[k].e[e]);
-                        float d = to_f<T>(g.v[k].e[e]) * inv_s;
+                        float d = to_f<T>(g.v[k].e[e]) * post;
                         if (xv == rmax) d += share_max;
                         if (xv == rmin) d += share_min;
                         g.v[k].e[e] = from_f<T>(d);
                     }
                 }
-            } else {
+            } else if (post != 1.f) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     if (!x.has(k)) continue;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) g.v[k].e[e] = from_f<T>(to_f<T>(g.v[k].e[e]) * inv_s);
+                    for (int e = 0; e < VEC; ++e) g.v[k].e[e] = from_f<T>(to_f<T>(g.v[k].e[e]) * post);
                 }
             }
 #pragma unroll

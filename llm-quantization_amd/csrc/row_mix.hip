@@ -118,7 +118,9 @@ __device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo
     const MixCtx c = mix_ctx(a, row, rmin, rmax);
     // instantiated per form of the level: a test inside the element loop would keep every form there
     auto quantize_row = [&](auto form_tag) {
-        constexpr int FORM = decltype(form_tag)::value;  // 2: plain row, 1: level_div, 0: IEEE division
+        // 3: plain row on ONE grid (an integer bit-width, as in the hard phase: weights 1 and 0, so 1 * fq_lo + 0 * fq_hi
+        // is fq_lo itself), 2: plain row, 1: level_div, 0: IEEE division
+        constexpr int FORM = decltype(form_tag)::value;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
@@ -126,13 +128,17 @@ __device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xv = x.v[k].e[e];
-                if constexpr (FORM == 2) o.e[e] = c.lo.w * plain_fq(xv, c.lo) + c.hi.w * plain_fq(xv, c.hi);
+                if constexpr (FORM == 3) o.e[e] = plain_fq(xv, c.lo);
+                else if constexpr (FORM == 2) o.e[e] = c.lo.w * plain_fq(xv, c.lo) + c.hi.w * plain_fq(xv, c.hi);
                 else o.e[e] = c.lo.w * grid_fq<FORM == 1>(xv, c.lo) + c.hi.w * grid_fq<FORM == 1>(xv, c.hi);
             }
             st_pack<float, VEC>(out + base + x.offset(k), o);
         }
     };
-    if (mix_plain_row(c, rmin, rmax)) quantize_row(std::integral_constant<int, 2>{});
+    if (mix_plain_row(c, rmin, rmax)) {
+        if (c.hi.w == 0.f) quantize_row(std::integral_constant<int, 3>{});
+        else quantize_row(std::integral_constant<int, 2>{});
+    }
     else if (level_div_ok(c.lo.s) && level_div_ok(c.hi.s)) quantize_row(std::integral_constant<int, 1>{});
     else quantize_row(std::integral_constant<int, 0>{});
 }
@@ -188,33 +194,58 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
     row_minmax(x, padded, lds, rmin, rmax, at_extreme);
     const MixCtx c = mix_ctx(a, row, rmin, rmax);
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dS_lo, dS_hi, over_lo, over_hi, #max, #min
-    // returns the straight-through part of dx through this grid (what autograd forms as ((g*w)*s)/s)
-    auto terms = [&](float xv, float gv, const Grid& gr, float& dS, float& over) {
-        const float gb = gv * gr.w;
-        // backward: the corrected reciprocal product without the range test of Divisor<float> (equal to the IEEE
-        // quotient for every weight a forward pass can quantize; gradients are tolerance-checked sums)
-        const float q0 = xv * gr.rs;
-        const float q = __builtin_fmaf(__builtin_fmaf(-q0, gr.s, xv), gr.rs, q0);
-        const float xi = ((rintf(q) - q) + q) + gr.z;
-        // the clamp as a median of three; the level lies inside the grid exactly when the clamp left it alone; a NaN
-        // level (the median drops it) reaches the sum through xi - xi, which is 0 for every other level
-        const float xc = __builtin_amdgcn_fmed3f(xi, 0.f, gr.Q);
-        const bool m = xc == xi;
-        const float xd = xc - gr.z;
-        dS += gb * (xd - (m ? q : xi - xi));
-        if (xi > gr.Q) over += gb * gr.s;
-        return m ? (gb * gr.s) * gr.rs : 0.f;
-    };
+    // An integer bit-width (every row of the hard phase) puts weight 1 on the lower grid and 0 on the upper one, whose
+    // terms vanish.  Such a row, when all of its levels are finite (mix_plain_row: a property of the row, tested once),
+    // takes a short form on ONE grid: rint(q) is its own straight-through form, no level is NaN, (g * s) / s is g to
+    // rounding, and the clamp term collects g alone (times s after the loop).
+    if (c.hi.w == 0.f && mix_plain_row(c, rmin, rmax)) {
+        const Grid& gr = c.lo;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (!x.has(k)) continue;
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xv = x.v[k].e[e], gv = g.v[k].e[e];
-            float d = 0.f;
-            d += terms(xv, gv, c.lo, acc[0], acc[2]);
-            d += terms(xv, gv, c.hi, acc[1], acc[3]);
-            g.v[k].e[e] = d;  // g is not read again: its registers carry the direct gradient to the dx pass
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = x.v[k].e[e], gv = g.v[k].e[e];
+                const float q0 = xv * gr.rs;
+                const float q = __builtin_fmaf(__builtin_fmaf(-q0, gr.s, xv), gr.rs, q0);
+                const float xi = rintf(q) + gr.z;
+                const float xc = __builtin_amdgcn_fmed3f(xi, 0.f, gr.Q);
+                const bool m = xc == xi;
+                acc[0] += gv * ((xc - gr.z) - (m ? q : 0.f));
+                acc[2] += (xi > gr.Q) ? gv : 0.f;
+                g.v[k].e[e] = m ? gv : 0.f;
+            }
+        }
+        acc[2] *= gr.s;
+    } else {
+        // returns the straight-through part of dx through this grid (what autograd forms as ((g*w)*s)/s)
+        auto terms = [&](float xv, float gv, const Grid& gr, float& dS, float& over) {
+            const float gb = gv * gr.w;
+            // backward: the corrected reciprocal product without the range test of Divisor<float> (equal to the IEEE
+            // quotient for every weight a forward pass can quantize; gradients are tolerance-checked sums)
+            const float q0 = xv * gr.rs;
+            const float q = __builtin_fmaf(__builtin_fmaf(-q0, gr.s, xv), gr.rs, q0);
+            const float xi = ((rintf(q) - q) + q) + gr.z;
+            // the clamp as a median of three; the level lies inside the grid exactly when the clamp left it alone; a NaN
+            // level (the median drops it) reaches the sum through xi - xi, which is 0 for every other level
+            const float xc = __builtin_amdgcn_fmed3f(xi, 0.f, gr.Q);
+            const bool m = xc == xi;
+            const float xd = xc - gr.z;
+            dS += gb * (xd - (m ? q : xi - xi));
+            if (xi > gr.Q) over += gb * gr.s;
+            return m ? (gb * gr.s) * gr.rs : 0.f;
+        };
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!x.has(k)) continue;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xv = x.v[k].e[e], gv = g.v[k].e[e];
+                float d = 0.f;
+                d += terms(xv, gv, c.lo, acc[0], acc[2]);
+                d += terms(xv, gv, c.hi, acc[1], acc[3]);
+                g.v[k].e[e] = d;  // g is not read again: its registers carry the direct gradient to the dx pass
+            }
         }
     }
     if (at_extreme) {  // the elements at the extremes are counted (and corrected, below) only by the lanes that hold them

@@ -609,6 +609,27 @@ def gather_lastdim(x, idx_i32):
     return out
 
 
+def gather_lastdim_batch(xs, idxs):
+    """[gather_lastdim(x, idx) for x, idx in zip(xs, idxs)] for up to 8 tensors of one shape and dtype in one launch."""
+    import ctypes
+    dev = L.check_gpu(*xs, *idxs)
+    C = xs[0].shape[-1]
+    for x, i in zip(xs, idxs):
+        if x.shape != xs[0].shape or x.dtype != xs[0].dtype:
+            raise L.MiqError("tensors of one batched gather must share shape and dtype")
+        if i.dtype != torch.int32 or i.numel() != C:
+            raise L.MiqError("gather index must be an int32 tensor with one entry per channel")
+    if len(idxs) != len(xs) or not 1 <= len(xs) <= 8:
+        raise L.MiqError(f"a batched gather takes 1..8 tensors with one index each, got {len(xs)} and {len(idxs)}")
+    R = xs[0].numel() // C if C else 0
+    outs = [torch.empty_like(x) for x in xs]
+    idx_tab = (ctypes.c_void_p * len(idxs))(*[i.data_ptr() for i in idxs])
+    with L.on_device(dev):
+        L.call("miq_gather_lastdim_batch", L.i32(len(xs)), _ptr_table(xs), idx_tab, _ptr_table(outs), L.i64(R), L.i64(C),
+               L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+    return outs
+
+
 class GatherLastDim(torch.autograd.Function):
     """index_select along the last axis by a permutation; the backward is the gather by the inverse."""
 

@@ -149,6 +149,22 @@ def test_gather_bit_exact(shape, dt):
     assert same(F.gather_lastdim(out, inv).cpu(), x)
 
 
+@pytest.mark.parametrize("shape,dt,n", [((1, 2048, 4096), "f16", 2), ((33, 70), "f32", 3), ((300, 1000), "f16", 8), ((5, 28672), "f32", 2)])
+def test_batched_gather_equals_one_gather_per_tensor(shape, dt, n):
+    """Several tensors of one shape, each through its own permutation, in one launch: the oracle's index_select per tensor,
+    bit for bit (the residual-stream gathers of a block's two reordered norms at the bench shape; ragged shapes; 8 tensors)."""
+    xs = [synth.activation(shape, 30 + i, DT[dt]) for i in range(n)]
+    idxs = [synth.permutation(shape[-1], 40 + i) for i in range(n)]
+    outs = F.gather_lastdim_batch([x.to(DEV) for x in xs], [i.to(torch.int32).to(DEV) for i in idxs])
+    for x, i, o in zip(xs, idxs, outs):
+        assert same(o.cpu(), O.gather_lastdim(x, i))
+    from miq._lib import MiqError
+    with pytest.raises(MiqError):
+        F.gather_lastdim_batch([xs[0].to(DEV)] * 9, [idxs[0].to(torch.int32).to(DEV)] * 9)
+    with pytest.raises(MiqError):
+        F.gather_lastdim_batch([xs[0].to(DEV), xs[0][..., :8].contiguous().to(DEV)], [idxs[0].to(torch.int32).to(DEV)] * 2)
+
+
 def test_gather_identity_and_wiring_fixture():
     d = golden("reorder")["wiring_small"]
     x3 = d["x3"].to(DEV)

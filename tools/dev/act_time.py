@@ -54,9 +54,9 @@ def main():
         tb = timed(bwd, side)
         tot_f += tf; tot_b += tb; nbytes += by
         name = "+".join(bench.SITES[i][0] for i in ids)
-        print(f"{name:24s} {str(xs[0].dtype)[6:]:8s} fwd {tf:7.2f} us {3 * by / tf / 1e6 / 8000:.3f}   bwd {tb:7.2f} us {3 * by / tb / 1e6 / 8000:.3f}")
-    print(f"{'step':24s} {'':8s} fwd {tot_f:7.2f} us {3 * nbytes / tot_f / 1e6 / 8000:.3f}   bwd {tot_b:7.2f} us {3 * nbytes / tot_b / 1e6 / 8000:.3f}"
-          f"   [MIQ_STAT_ROWS={os.environ.get('MIQ_STAT_ROWS', '-')} MIQ_STAT_DEPTH={os.environ.get('MIQ_STAT_DEPTH', '-')}]")
+        print(f"{name:24s} {str(xs[0].dtype)[6:]:8s} fwd {tf:7.2f} us {3 * by / tf / 1e3 / 8000:.3f}   bwd {tb:7.2f} us {3 * by / tb / 1e3 / 8000:.3f}")
+    print(f"{'step':24s} {'':8s} fwd {tot_f:7.2f} us {3 * nbytes / tot_f / 1e3 / 8000:.3f}   bwd {tot_b:7.2f} us {3 * nbytes / tot_b / 1e3 / 8000:.3f}"
+          f"   [{' '.join(k + '=' + v for k, v in os.environ.items() if k.startswith('MIQ_'))}]")
 
 
 if __name__ == "__main__":
