@@ -420,7 +420,7 @@ struct SlotParams {
 template <typename T, int VEC, int DEPTH, int NREP, bool UNIFORM>
 __global__ void __launch_bounds__(256)
 k_colquant_slots(SlabPtrs xs, SlotMap sm, u64* ws_base, long long ws_stride, SlabOuts outs, SlabOuts codes_tab, SlabOuts vecs,
-                 long long R, int C, int rows_per_chunk, float qmax) {
+                 long long R, int C, int rows_per_chunk, float qmax, int stream_out) {
     constexpr int NP = UNIFORM ? 1 : VEC;  // parameter sets per lane
     const T* __restrict__ x = static_cast<const T*>(xs.p[blockIdx.z]);
     T* __restrict__ out = static_cast<T*>(outs.p[blockIdx.z]);
@@ -491,8 +491,8 @@ k_colquant_slots(SlabPtrs xs, SlotMap sm, u64* ws_base, long long ws_stride, Sla
                 o.e[e] = from_f<T>(affine_dequant<T>(xc, s[k], z[k], EX));
                 if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
             }
-            st_pack<T, VEC>(out + rr * C + col0, o);
-            if (codes) st_pack<uint8_t, VEC>(codes + rr * C + col0, cd);
+            st_out<T, VEC>(out + rr * C + col0, o, stream_out);
+            if (codes) st_out<uint8_t, VEC>(codes + rr * C + col0, cd, stream_out);
         };
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u)
@@ -749,17 +749,18 @@ template <typename T, int VEC, int NREP>
 static void launch_fresh_quant(bool uniform, dim3 grid, hipStream_t stream, const SlabPtrs& xs, const SlotMap& sm, u64* ws,
                                long long ws_stride, const SlabOuts& outs, const SlabOuts& codes, const SlabOuts& vecs, long long R,
                                int C, int rpc, float qmax) {
+    const int stream_out = stream_out_of(R * C * (long long)sizeof(T) * grid.z);  // all slabs of the launch
     // a single fp32 slab is short of loads in flight with four rows per wave (25 -> 21 us for [2048, 4096]); with two or
     // three slabs per launch the larger batch only costs occupancy (21 -> 22 us per slab)
     if (uniform && sizeof(T) == 4 && grid.z == 1)
         hipLaunchKernelGGL((k_colquant_slots<T, VEC, 8, NREP, true>), grid, dim3(256), 0, stream, xs, sm, ws, ws_stride, outs, codes,
-                           vecs, R, C, rpc, qmax);
+                           vecs, R, C, rpc, qmax, stream_out);
     else if (uniform)
         hipLaunchKernelGGL((k_colquant_slots<T, VEC, 4, NREP, true>), grid, dim3(256), 0, stream, xs, sm, ws, ws_stride, outs, codes,
-                           vecs, R, C, rpc, qmax);
+                           vecs, R, C, rpc, qmax, stream_out);
     else
         hipLaunchKernelGGL((k_colquant_slots<T, VEC, 4, NREP, false>), grid, dim3(256), 0, stream, xs, sm, ws, ws_stride, outs, codes,
-                           vecs, R, C, rpc, qmax);
+                           vecs, R, C, rpc, qmax, stream_out);
 }
 
 template <typename T>

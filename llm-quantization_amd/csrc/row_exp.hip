@@ -165,7 +165,7 @@ __device__ __forceinline__ void exp2_fwd_row(const ExpArgs<T>& a, const RowGeom&
                     Pack<T, VEC> o;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_plain_level<SMALL>(to_f<T>(x.v[k].e[e]), c, rs) * c.s);
-                    st_pack<T, VEC>(out + base + x.offset(k), o);
+                    st_out<T, VEC>(out + base + x.offset(k), o, geo.stream_out);
                 }
             };
             if (a.n_bits <= 3) plain_row(std::true_type{});
@@ -179,7 +179,7 @@ __device__ __forceinline__ void exp2_fwd_row(const ExpArgs<T>& a, const RowGeom&
         Pack<T, VEC> o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp2_elem<T>(to_f<T>(x.v[k].e[e]), c, dv).signed_lvl * c.s);
-        st_pack<T, VEC>(out + base + x.offset(k), o);
+        st_out<T, VEC>(out + base + x.offset(k), o, geo.stream_out);
     }
 }
 
@@ -346,7 +346,7 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 if (!x.has(k)) continue;
-                st_pack<T, VEC>(dx + base + x.offset(k), g.v[k]);
+                st_out<T, VEC>(dx + base + x.offset(k), g.v[k], geo.stream_out);
             }
         }
         return;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);
             }
-            st_pack<T, VEC>(dx + base + x.offset(k), o);
+            st_out<T, VEC>(dx + base + x.offset(k), o, geo.stream_out);
         }
     }
 }
@@ -541,7 +541,7 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
                     Pack<T, VEC> o;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_plain_out<SMALL>(to_f<T>(x.v[k].e[e]), c, rs));
-                    st_pack<T, VEC>(out + base + x.offset(k), o);
+                    st_out<T, VEC>(out + base + x.offset(k), o, geo.stream_out);
                 }
             };
             if (a.n_bits <= 3) plain_row(std::true_type{});
@@ -555,7 +555,7 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
         Pack<T, VEC> o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o.e[e] = from_f<T>(exp1_out<T>(exp1_elem<T>(to_f<T>(x.v[k].e[e]), c, dv), c));
-        st_pack<T, VEC>(out + base + x.offset(k), o);
+        st_out<T, VEC>(out + base + x.offset(k), o, geo.stream_out);
     }
 }
 
@@ -702,7 +702,7 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 if (!x.has(k)) continue;
-                st_pack<T, VEC>(dx + base + x.offset(k), g.v[k]);
+                st_out<T, VEC>(dx + base + x.offset(k), g.v[k], geo.stream_out);
             }
         }
         return;
@@ -726,7 +726,7 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);
             }
-            st_pack<T, VEC>(dx + base + x.offset(k), o);
+            st_out<T, VEC>(dx + base + x.offset(k), o, geo.stream_out);
         }
     }
 }
@@ -745,6 +745,7 @@ static int launch_exp(int which, bool backward, const void* gout, const void* x,
     MIQ_CHECK_ARG(!backward || !up || (a1 && a2), "%s: d_up/d_low required when up/low are given", name);
     RowGeom geo;
     MIQ_CHECK_ARG(make_geom(O, I, group, geo), "%s: matrix too large", name);
+    geo.stream_out = stream_out_of(O * I * (long long)sizeof(T));
     constexpr int N = VecOf<T>::N;
     const bool vec_ok = (I % N == 0) && (geo.g % N == 0) && is_aligned16(x) && (!out_or_dx || is_aligned16(out_or_dx)) &&
                         (!backward || is_aligned16(gout));
@@ -809,6 +810,7 @@ static int launch_exp2_batch(bool backward, int n, const void* const* gout, cons
     geo.g = (int)I;
     geo.G = 1;
     geo.n_rows = rows;
+    geo.stream_out = stream_out_of(rows * I * (long long)sizeof(T));
     ExpArgs<T> a{};
     a.n_bits = n_bits;
     a.symmetric = 1;

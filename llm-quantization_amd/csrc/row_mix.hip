@@ -132,7 +132,7 @@ __device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo
                 else if constexpr (FORM == 2) o.e[e] = c.lo.w * plain_fq(xv, c.lo) + c.hi.w * plain_fq(xv, c.hi);
                 else o.e[e] = c.lo.w * grid_fq<FORM == 1>(xv, c.lo) + c.hi.w * grid_fq<FORM == 1>(xv, c.hi);
             }
-            st_pack<float, VEC>(out + base + x.offset(k), o);
+            st_out<float, VEC>(out + base + x.offset(k), o, geo.stream_out);
         }
     };
     if (mix_plain_row(c, rmin, rmax)) {
@@ -301,7 +301,7 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!x.has(k)) continue;
-            st_pack<float, VEC>(dx + base + x.offset(k), g.v[k]);
+            st_out<float, VEC>(dx + base + x.offset(k), g.v[k], geo.stream_out);
         }
     }
 }
@@ -346,6 +346,7 @@ static int launch_mix(bool backward, const void* gout, const void* x, const void
     MIQ_CHECK_ARG(!backward || !up || (d_up && d_low), "%s: d_up/d_low required when up/low are given", name);
     RowGeom geo;
     MIQ_CHECK_ARG(make_geom(O, I, group, geo), "%s: matrix too large", name);
+    geo.stream_out = stream_out_of(O * I * (long long)sizeof(float));
     const bool vec_ok = (I % 4 == 0) && (geo.g % 4 == 0) && is_aligned16(x) && (!out_or_dx || is_aligned16(out_or_dx)) &&
                         (!backward || is_aligned16(gout));
     MIQ_CHECK_ARG((vec_ok ? geo.g / 4 : geo.g) <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
@@ -411,6 +412,7 @@ static int launch_mix_batch(bool backward, int n, const void* const* gout, const
     geo.g = (int)I;
     geo.G = 1;
     geo.n_rows = rows;
+    geo.stream_out = stream_out_of(rows * I * (long long)sizeof(float));
     MixArgs a{};
     a.symmetric = symmetric;
     a.hard = hard;

@@ -112,7 +112,7 @@ __device__ __forceinline__ void uniform_fwd_row(const UniArgs<T>& a, const RowGe
                 if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
             }
             const long long off = base + x.offset(k);
-            st_pack<T, VEC>(out + off, o);
+            st_out<T, VEC>(out + off, o, geo.stream_out);
             if (codes) st_pack<uint8_t, VEC>(codes + off, cd);
         }
     };
@@ -282,7 +282,7 @@ __device__ __forceinline__ void uniform_bwd_row(const UniArgs<T>& a, const RowGe
                 if (xv == rmin) d += share_min;
                 o.e[e] = from_f<T>(d);
             }
-            st_pack<T, VEC>(dx + base + x.offset(k), o);
+            st_out<T, VEC>(dx + base + x.offset(k), o, geo.stream_out);
         }
     }
 }
@@ -354,6 +354,7 @@ static int launch_uniform(bool backward, const void* gout, const void* x, const 
     geo.g = group > 0 ? (int)group : (int)I;
     geo.G = (int)((I + geo.g - 1) / geo.g);
     geo.n_rows = O * geo.G;
+    geo.stream_out = stream_out_of(O * I * (long long)sizeof(T));
     MIQ_CHECK_ARG(I < (1ll << 31) && geo.n_rows < (1ll << 31) * 4, "%s: matrix too large", name);
     constexpr int N = VecOf<T>::N;
     bool vec_ok = (I % N == 0) && (geo.g % N == 0) && aligned16(x) && aligned16(out_or_dx) &&
@@ -462,6 +463,7 @@ static int launch_uniform_batch(bool backward, int n, const void* const* gout, c
     geo.g = (int)I;
     geo.G = 1;
     geo.n_rows = rows;
+    geo.stream_out = stream_out_of(rows * I * (long long)sizeof(T));
     UniArgs<T> a{};
     a.row_bits = nullptr;  // the kernels with bit-width vectors set it per matrix
     a.n_bits = n_bits;
