@@ -46,7 +46,7 @@ extern "C" {
  * raw factors and a flag bit 1 for this form; the bit is ignored now.) */
 
 /* major*10000 + minor*100 + patch of this interface; it grows when an entry point is added or a signature changes
- * (301: miq_gather_lastdim_batch; 300: up / low are the activated clip factors in every row-wise entry point; 200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
+ * (302: miq_act_static_init; 301: miq_gather_lastdim_batch; 300: up / low are the activated clip factors in every row-wise entry point; 200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
  * miq_act_quant_from_table, miq_gather_layernorm_bwd, miq_act_calib_quant_fwd_static) */
 int miq_version(void);
 const char* miq_last_error(void);
@@ -227,8 +227,12 @@ int miq_act_fresh_quant_bwd(int n, const void* const* grad_out, const void* cons
  * optional fp32 [C], receive the per-channel statistics before the cluster merge (the chan_min / chan_max inputs
  * of miq_colquant_bwd).  The tensors' device must be the current device.  All calls on one GPU share that GPU's
  * array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream are safe.
+ * The device address of the array is looked up once per GPU (hipGetSymbolAddress: no allocation, but not a stream
+ * operation either): by miq_act_static_init() with that GPU current, at set-up, or else by the first call there, which
+ * must then not run under stream capture.  miq_act_static_init returns 0 or -5.
  */
 int64_t miq_act_static_capacity(void);
+int miq_act_static_init(void);
 int miq_act_calib_quant_fwd_static(const void* x, const void* cached_min, const void* cached_max, int metric,
                                    const int* starts, int n_clusters, int64_t covered, int n_bits, void* out,
                                    void* codes_out, void* cmin_out, void* cmax_out, void* scale_out, void* zp_out,

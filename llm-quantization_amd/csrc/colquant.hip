@@ -185,8 +185,8 @@ __global__ void __launch_bounds__(256) k_cluster_scale(ScaleArgs<T> a) {
     const float qmax = exp2f((float)a.n_bits) - 1.0f;
     const float lo = rnd<T>(kClipLo);
     for (int c = st + blockIdx.y * 256 + threadIdx.x; c < en; c += 256 * gridDim.y) {
-        const float mn = own ? cmn[c] : mm[0];
-        const float mx = own ? cmx[c] : mm[1];
+        const float mn = (own ? cmn[c] : mm[0]) + 0.f;  // a zero extreme is +0 (see max_key)
+        const float mx = (own ? cmx[c] : mm[1]) + 0.f;
         a.cmin_out[c] = from_f<T>(mn);
         a.cmax_out[c] = from_f<T>(mx);
         const float s = clampf(rnd<T>(rnd<T>(mx - mn) / qmax), lo, kClipHi);
@@ -920,6 +920,11 @@ static int static_scratch(float** out) {
 }
 
 extern "C" int64_t miq_act_static_capacity(void) { return kStaticScratchFloats; }
+
+extern "C" int miq_act_static_init(void) {
+    float* ws = nullptr;
+    return static_scratch(&ws);
+}
 
 extern "C" int miq_act_calib_quant_fwd_static(const void* x, const void* cached_min, const void* cached_max, int metric,
                                               const int* starts, int n_clusters, int64_t covered, int n_bits,

@@ -17,10 +17,12 @@ namespace miq {
 
 typedef unsigned long long u64;
 
-// order-preserving key of a float for an unsigned maximum; NaN maps to the largest key (it wins, like torch.amax)
+// order-preserving key of a float for an unsigned maximum; NaN maps to the largest key (it wins, like torch.amax).
+// A zero enters as +0 (the keys would order -0 below +0, where the float comparisons of the partial-plane kernels
+// keep whichever zero came first: k_cluster_scale canonicalises the same way, so the two paths agree in every bit).
 __device__ __forceinline__ unsigned max_key(float f) {
     if (f != f) return 0xFFFFFFFFu;
-    const unsigned u = __float_as_uint(f);
+    const unsigned u = __float_as_uint(f + 0.f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float max_key_value(unsigned k) {

@@ -277,3 +277,27 @@ def test_infinite_nan_and_huge_activations_match_the_oracle(dt, counts):
         assert torch.equal(codes[0].cpu().to(torch.int32), torch.nan_to_num(ref_codes, nan=0.0).to(torch.int32)), special
         o_out, o_codes, o_st = F.act_calib_quant_fwd(xd, 4, "minmax", layout, want_codes=True)
         assert same(o_out.cpu(), ref) and torch.equal(o_codes, codes[0]), special
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_signed_zero_extremes_give_the_same_bits_on_both_paths(dt):
+    """A cluster whose minimum (or maximum) is zero, present as -0 and +0: float comparisons keep whichever zero came
+    first, integer keys order -0 below +0; both paths report +0, so statistics, zero points and outputs agree in every
+    bit, sign of zero included."""
+    dtype = DT[dt]
+    R, C, bits, counts = 96, 256, 4, [64] * 4
+    layout = F.ClusterLayout.get(counts, C, DEV)
+    x = torch.relu(synth.activation((R, C), 910, dtype)).to(dtype)
+    x[::3] = x[::3] * -0.0 + torch.where(x[::3] > 0, x[::3], torch.zeros_like(x[::3]))  # -0 where relu cut, values kept
+    x[1::3, :64] = -torch.relu(-synth.activation((R, C), 911, dtype))[1::3, :64].to(dtype)  # cluster 0: maximum zero
+    x[0, 5] = -0.0
+    x[2, 5] = 0.0
+    xd = x.to(DEV)
+    outs, _codes, vecs = F.act_fresh_quant_fwd([xd], bits, layout)
+    o_out, _c, o_st = F.act_calib_quant_fwd(xd, bits, "minmax", layout)
+    bits_of = lambda t: t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int16)
+    assert torch.equal(bits_of(outs[0]), bits_of(o_out))
+    for k, row in (("cmin", 0), ("cmax", 1), ("scale", 2), ("zp", 3), ("rzp", 4)):
+        assert torch.equal(bits_of(vecs[0][row]), bits_of(o_st[k])), k
+    for row in (0, 1):  # a zero extreme is +0
+        assert not (torch.signbit(vecs[0][row]) & (vecs[0][row] == 0)).any()

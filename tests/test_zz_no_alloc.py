@@ -83,3 +83,46 @@ def test_static_scratch_refuses_slabs_beyond_its_capacity():
     lay = F.ClusterLayout.get([64] * 4, 256, DEV)
     a, b = _call(True, y, 4, "minmax", lay), _call(False, y, 4, "minmax", lay)
     assert _same(a["out"], b["out"]) and _same(a["scale"], b["scale"])
+
+
+def test_static_entry_point_allocates_nothing_and_runs_under_stream_capture():
+    """After miq_act_static_init() the call makes no device allocation: free device memory is unchanged across it, and
+    it can be captured into a HIP graph (an allocation would end the capture with an error) whose replay gives the
+    bits of the eager call."""
+    with L.on_device(torch.device(DEV)):
+        L.call("miq_act_static_init")
+    shape, counts, bits = (512, 1024), [128] * 8, 4
+    x = synth.activation(shape, 731, torch.float32).to(DEV)
+    layout = F.ClusterLayout.get(counts, shape[1], DEV)
+    ref = _call(False, x, bits, "minmax", layout)
+    R, C = shape
+    out = torch.empty_like(x)
+    codes = torch.empty((R, C), dtype=torch.uint8, device=DEV)
+    vec = torch.empty((5, C), dtype=x.dtype, device=DEV)
+    chan = torch.empty((2, C), dtype=torch.float32, device=DEV)
+    side = torch.cuda.Stream()
+
+    def call():
+        L.call("miq_act_calib_quant_fwd_static", L.ptr(x), L.ptr(None), L.ptr(None), L.i32(0), L.ptr(layout.starts),
+               L.i32(layout.n_clusters), L.i64(layout.covered), L.i32(bits), L.ptr(out), L.ptr(codes), L.ptr(vec[0]),
+               L.ptr(vec[1]), L.ptr(vec[2]), L.ptr(vec[3]), L.ptr(vec[4]), L.ptr(chan[0]), L.ptr(chan[1]), L.i64(R), L.i64(C),
+               L.i32(L.dtype_code(x)), L.stream_of(x))
+
+    with torch.cuda.stream(side):
+        call()  # the stream's own first launch lets the runtime set up its queue
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    with torch.cuda.stream(side):
+        call()
+    side.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    assert _same(out, ref["out"]) and _same(vec[2], ref["scale"])
+    out.zero_()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        call()
+    g.replay()
+    torch.cuda.synchronize()
+    assert _same(out, ref["out"]) and _same(codes, ref["codes"]) and _same(vec[4], ref["rzp"])
+    assert _same(chan[0], ref["chan_min"]) and _same(chan[1], ref["chan_max"])
