@@ -14,7 +14,7 @@ python3 -c "import sys; sys.path.insert(0, 'llm-quantization_amd'); from miq imp
 echo "[collect] bench"; timeout -k 10 600 python3 -u bench.py > "$D/bench.json.log" 2> "$D/bench.err"
 cd /tmp
 echo "[collect] kernel trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-block-calib > "$D/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-block-calib --no-families > "$D/trace.log" 2>&1
 echo "[collect] pmc fetch"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -- python3 "$R/bench.py" --eager --steps 2 --warmup 1 --no-cpu-baseline --no-block-calib --no-families > "$D/fetch.log" 2>&1
 echo "[collect] pmc write"
