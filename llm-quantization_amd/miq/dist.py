@@ -93,10 +93,22 @@ def allreduce_mean_grads(params: Iterable[torch.nn.Parameter], ctx: DPContext, b
         if p.grad is None:
             p.grad = torch.zeros_like(p)
     grads = [p.grad for p in params]
-    torch._foreach_copy_(buf.views, grads)
+    # The multi-tensor copy is only taken when no pair converts: on this PyTorch 2.10 / ROCm 7 build
+    # torch._foreach_copy_ returns wrong values for the fp16 tensors of a list that mixes fp32 -> fp32 and
+    # fp32 -> fp16 pairs, and for the tensors after them (tools/dev/foreach_copy_check.py).
+    fused = all(g.dtype == torch.float32 for g in grads)
+    if fused:
+        torch._foreach_copy_(buf.views, grads)
+    else:
+        for v, g in zip(buf.views, grads):
+            v.copy_(g)
     dist.all_reduce(buf.flat, op=dist.ReduceOp.SUM, group=ctx.group)
     buf.flat.div_(ctx.world)
-    torch._foreach_copy_(grads, buf.views)
+    if fused:
+        torch._foreach_copy_(grads, buf.views)
+    else:
+        for g, v in zip(grads, buf.views):
+            g.copy_(v)
     return buf
 
 

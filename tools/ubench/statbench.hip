@@ -1,5 +1,5 @@
 // Development micro-benchmark: where the statistics kernel of the activation quantizer loses time against a pure
-// read of the same geometry.  MODE 0 = library kernel, 1 = call counter requested first, 2 = no publish tail
+// read of the same geometry.  MODE 0 = the kernel's first form, 1 = call counter requested first, 2 = no publish tail
 // (upper bound), 3 = counter first + uniform-slot tail.
 //   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I../../llm-quantization_amd/csrc statbench.hip -o statbench
 #include <algorithm>
@@ -197,7 +197,12 @@ static void run_shape(const char* label, long long R, int C, int cluster, int ns
 #define RUN(MODE, DEPTH, name) { \
         const float t = time_graph([&] { for (int g = 0; g < groups; ++g) hipLaunchKernelGGL((k_stat_x<T, N, DEPTH, MODE>), grid, dim3(256), 0, g_stream, slabs(g), R, C, rpc, sm, ws, ws_stride, nrep); }) / groups; \
         printf("  %-34s %7.2f us  %5.2f TB/s\n", name, t, nslab * mb / t); }
-    RUN(0, 4, "library kernel");
+    {   // what the library launches for this shape (act_fresh_t): uniform slots, 8 rows in flight in fp32, 4 in fp16
+        constexpr int D = sizeof(T) == 4 ? 8 : 4;
+        const float t = time_graph([&] { for (int g = 0; g < groups; ++g) hipLaunchKernelGGL((k_colstat_slots<T, N, D, true>), grid, dim3(256), 0, g_stream, slabs(g), (long long)R, C, rpc, sm, ws, ws_stride, nrep); }) / groups;
+        printf("  %-34s %7.2f us  %5.2f TB/s\n", "k_colstat_slots as shipped", t, nslab * mb / t);
+    }
+    RUN(0, 4, "first form (per-channel tail)");
     RUN(1, 4, "counter first");
     RUN(2, 4, "counter first, no publish");
     RUN(3, 4, "counter first, uniform tail");
