@@ -625,6 +625,9 @@ def launch_ranks(n: int, argv):
 
 
 def main():
+    if os.environ.get("MIQ_BENCH_STACKS"):  # every rank dumps its Python stacks every N seconds (where does a rank wait?)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MIQ_BENCH_STACKS"]), repeat=True, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -708,10 +711,9 @@ def main():
         torch.cuda.empty_cache()
     if world > 1:
         barrier()
-    want_blk = not args.no_block_calib and (world == 1 or not rehearsal or args.block_calib)
-    blk = block_calib(dev, world, rank, rehearsal) if want_blk else None
 
-    if rank == 0:
+    def emit(blk):
+        """Rank 0's result line."""
         by = by_local
         step_bytes = sum(by.values())
         totals = totals_local
@@ -777,6 +779,33 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
         print(json.dumps(out))
+
+    want_blk = not args.no_block_calib and (world == 1 or not rehearsal or args.block_calib)
+    blk = None
+    if want_blk and world > 1:
+        # The data-parallel block calibration runs collectives in a loop.  Should a rank ever wait in one for good, the
+        # result line must still appear: past the deadline rank 0 prints it with an error object in place of the
+        # measurement, and every rank leaves without waiting for the others.
+        import threading
+        finished = threading.Event()
+        deadline = float(os.environ.get("MIQ_BENCH_BLOCK_DEADLINE", "420"))
+
+        def watchdog():
+            if finished.wait(deadline):
+                return
+            if rank == 0:
+                emit({"error": f"the data-parallel block calibration did not finish within {deadline:.0f} s; the run was ended"})
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        blk = block_calib(dev, world, rank, rehearsal)
+        finished.set()
+    elif want_blk:
+        blk = block_calib(dev, world, rank, rehearsal)
+    if rank == 0:
+        emit(blk)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import functional as MF
 from . import reorder_utils as R
-from .dist import DPContext, allreduce_mean_grads, broadcast_from, sample_owner
+from .dist import DPContext, all_reduce, allreduce_mean_grads, broadcast_from, sample_owner
 from .int_linear import QuantLinear
 from .int_matmul import QuantMatMul
 from .omni_norm import OmniLayerNorm
@@ -142,7 +142,7 @@ def sync_reorder_stats(dp: Optional[DPContext]):
         if not names:
             continue
         packed = torch.cat([torch.cat((store[n][0].float(), -store[n][1].float())) for n in names])
-        dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=dp.group)
+        all_reduce(packed, dist.ReduceOp.MAX, dp.group)
         off = 0
         for n in names:
             c = store[n][0].numel()

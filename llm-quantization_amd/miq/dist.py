@@ -62,6 +62,44 @@ def sample_owner(index: int, world: int):
     return index % world, index // world
 
 
+# Collectives.  On RCCL ("nccl") GPU tensors go to the collective as they are.  The gloo backend is what the CPU tests
+# and the one-GPU rehearsals of N ranks use; its own path for GPU tensors stalled now and then when two ranks shared one
+# GPU (both ranks inside the same all-reduce until the 60 s timeout: seen twice in three rehearsals of bench.py), so under
+# gloo a GPU tensor makes the trip through a host copy.
+def _staged(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce(t: torch.Tensor, op, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def broadcast(t: torch.Tensor, src: int, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def all_gather_into(out: torch.Tensor, part: torch.Tensor, group=None):
+    if _staged(out, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, part.cpu(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, part, group=group)
+    return out
+
+
 class GradBucket:
     """One flat fp32 buffer with a view per parameter: packing and unpacking are one multi-tensor copy each."""
 
@@ -102,7 +140,7 @@ def allreduce_mean_grads(params: Iterable[torch.nn.Parameter], ctx: DPContext, b
     else:
         for v, g in zip(buf.views, grads):
             v.copy_(g)
-    dist.all_reduce(buf.flat, op=dist.ReduceOp.SUM, group=ctx.group)
+    all_reduce(buf.flat, dist.ReduceOp.SUM, ctx.group)
     buf.flat.div_(ctx.world)
     if fused:
         torch._foreach_copy_(grads, buf.views)
@@ -117,7 +155,7 @@ def allreduce_minmax(cmin: torch.Tensor, cmax: torch.Tensor, ctx: DPContext):
     if not ctx.active:
         return cmin, cmax
     packed = torch.cat((-cmin, cmax))
-    dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=ctx.group)
+    all_reduce(packed, dist.ReduceOp.MAX, ctx.group)
     c = cmin.numel()
     cmin.copy_(-packed[:c])
     cmax.copy_(packed[c:])
@@ -126,7 +164,7 @@ def allreduce_minmax(cmin: torch.Tensor, cmax: torch.Tensor, ctx: DPContext):
 
 def broadcast_from(t: torch.Tensor, src: int, ctx: DPContext):
     if ctx.active:
-        dist.broadcast(t, src=src, group=ctx.group)
+        broadcast(t, src, ctx.group)
     return t
 
 
@@ -157,13 +195,13 @@ def gather_row_shards(shard: torch.Tensor, rows_total: int, ctx: DPContext, out:
     if shard.shape[0] != b - a:
         raise ValueError(f"rank {ctx.rank} holds {shard.shape[0]} rows, its range [{a}, {b}) has {b - a}")
     if rows_total % ctx.world == 0:
-        dist.all_gather_into_tensor(out, shard.contiguous(), group=ctx.group)
+        all_gather_into(out, shard.contiguous(), ctx.group)
         return out
     most = -(-rows_total // ctx.world)
     padded = torch.zeros((most, *cols), dtype=shard.dtype, device=shard.device)
     padded[:b - a].copy_(shard)
     stage = torch.empty((ctx.world * most, *cols), dtype=shard.dtype, device=shard.device)
-    dist.all_gather_into_tensor(stage, padded, group=ctx.group)
+    all_gather_into(stage, padded, ctx.group)
     stage = stage.view(ctx.world, most, *cols)
     for r in range(ctx.world):
         ra, rb = shard_range(rows_total, r, ctx.world)

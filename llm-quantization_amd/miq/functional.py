@@ -587,8 +587,9 @@ def colquant_bwd(g2d, x2d, scale, rzp, n_bits: int, route=None, dp=None):
     with L.on_device(dev):
         if route is not None and dp is not None and dp.active and dp.sync_stats:
             import torch.distributed as tdist
+            from .dist import all_reduce
             L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(1), flat, code, st)
-            tdist.all_reduce(ws[3 * nchunk * C:(3 * nchunk + 3) * C], group=dp.group)  # [dS, #max, #min] per channel
+            all_reduce(ws[3 * nchunk * C:(3 * nchunk + 3) * C], tdist.ReduceOp.SUM, dp.group)  # [dS, #max, #min] per channel
             L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(2), flat, code, st)
         else:
             L.call("miq_colquant_bwd", L.ptr(g2d), L.ptr(x2d), L.ptr(scale), L.ptr(rzp), *args, *tail, L.i32(0), flat, code, st)
