@@ -87,9 +87,10 @@ __device__ __forceinline__ Exp2Elem exp2_elem(float xv, const Exp2Ctx& c, const 
 // In the reference's float arithmetic t = fl(fl(log2 y) + 0.5) the addition rounds too, which moves each threshold by a
 // few ulp: with a correctly rounded log2 the float just below 3 already gives t = 1.5 and level 4, while 1.5 and 6 stay
 // on the lower level.  Up to 3 bits (levels 0, 1, 2, 4, and "beyond the top") three or four compare-and-selects against
-// those exact floats replace divide, log2, round, ldexp.  From 4 bits on the exponent field of y decides; there an
-// element within 5 ulp of a threshold may land on the neighbouring level (the stated tolerance of the exponent grids,
-// the same the logarithm instruction has).
+// those exact floats replace divide, log2, round, ldexp.  From 4 bits on the exponent field of y decides, with the
+// same exactness (exp2_level_of).  Rows that are not plain, and fp16 rows, go through the logarithm instruction, whose
+// last bit may put an element within a few ulp of a threshold on the neighbouring level (the stated tolerance of the
+// exponent grids).
 __device__ __forceinline__ bool exp2_plain_row(const Exp2Ctx& c, float rmin, float rmax) {
     const float bound = __builtin_fmaxf(fabsf(rmin), fabsf(rmax)) / c.s;
     return (rmin == rmin) && (rmax == rmax) && (bound <= 0x1p60f);  // a NaN scale gives a NaN bound
@@ -100,11 +101,18 @@ __device__ __forceinline__ float exp2_level_of(float a0) {
     if constexpr (SMALL) {  // n_bits <= 3: top <= 4; 8 stands for every level beyond it
         return a0 <= 1.5f ? 1.f : (a0 < 0x1.7ffffep+1f ? 2.f : (a0 <= 6.f ? 4.f : 8.f));  // 0x1.7ffffep+1: the float below 3
     } else {
+        // y in [2^j, 2^(j+1)) has level 2^(j+1), except within an ulp or two of the ends of the interval, where the
+        // rounding of fl(log2 y) + 0.5 decides (a correctly rounded log2; found by brute force over +-16 ulp of every
+        // power of two): the lower end of an even j stays on level 2^j for the first d floats, its upper end is on
+        // level 2^(j+2) for the last d floats, d = 1 for j < 4 and 2 for j = 4, 6; an odd j has no exceptions.  (From
+        // j = 8 on the offsets grow to 3 and 5 ulp; those levels lie beyond the top of every supported bit-width.)
         const unsigned b = __float_as_uint(div_1p5(__builtin_amdgcn_fmed3f(a0, 1e-4f, 1e4f)));  // y > 0
-        const int eb = (int)(b >> 23);                                    // biased exponent
-        const int inc = (b & 0x7FFFFFu) ? 1 : ((eb & 1) ^ 1);            // above 2^j: next power; at 2^j: j + (j & 1), j = eb - 127
-        int kb = eb + inc;
-        kb = kb < 127 ? 127 : kb;                                         // y < 0.5 (t < -0.5 in the reference): level 2^0
+        const int eb = (int)(b >> 23);  // biased exponent, j = eb - 127
+        const unsigned m = b & 0x7FFFFFu;
+        const unsigned d = eb < 127 + 4 ? 1u : 2u;
+        const int even = (eb & 1);      // eb odd <=> j even
+        int kb = eb + 1 + (even ? (int)(m >= 0x800000u - d) - (int)(m < d) : 0);
+        kb = kb < 127 ? 127 : kb;       // y < 1: level 2^0 (incl. the reference's branch t < -0.5)
         return __uint_as_float((unsigned)kb << 23);
     }
 }
@@ -465,18 +473,31 @@ __device__ __forceinline__ bool exp1_plain_row(const Exp1Ctx& c, float rmin, flo
 // 2^(k - 0.5) < a < 2^(k + 0.5).  The thresholds are irrational, so which of the two floats around one is the first of
 // the upper level is decided by the last bit of fl(log2 a); kExp1From[j] is the first float that a correctly rounded
 // log2 sends to level 2^-j.  Up to 3 bits (levels 1, 1/2, 1/4, 1/8) three compare-and-selects against those floats; from
-// 4 bits on the exponent field and a comparison of the significand with sqrt(2), where an element within a few ulp of
-// a threshold may land on the neighbouring level (the stated tolerance of the exponent grids).
+// 4 bits on the exponent field and a comparison of the significand with the boundary's own first float.  Rows that are
+// not plain, and fp16 rows, go through the logarithm instruction, whose last bit may put an element within a few ulp
+// of a threshold on the neighbouring level (the stated tolerance of the exponent grids).
 __device__ constexpr float kExp1From[4] = {0x1.6a09e6p-1f, 0x1.6a09e8p-2f, 0x1.6a09e6p-3f, 0x1.6a09eap-4f};
 constexpr float kExp1Above = 0x1.6a09e8p+0f;  // the first float whose log2 rounds to 1
+// the first float of level 2^k, k in [-16, 1] (see exp1_level_of)
+__device__ __forceinline__ float exp1_first_of(int k) {
+    const int idx = k + 16 < 0 ? 0 : (k + 16 > 17 ? 17 : k + 16);
+    const unsigned off = (unsigned)((idx < 16 ? 0x8796a6a4c4c4c4c0ull >> (4 * idx) : 0x87ull >> (4 * (idx - 16))) & 15u);
+    return __uint_as_float(((unsigned)(k - 1 + 127) << 23) | (0x3504ECu + off));
+}
 template <bool SMALL>
 __device__ __forceinline__ float exp1_level_of(float a, const Exp1Ctx& c) {
     if constexpr (SMALL) {
         const float p = a >= 0x1.6a09e6p-1f ? 1.f : (a >= 0x1.6a09e8p-2f ? 0.5f : (a >= 0x1.6a09e6p-3f ? 0.25f : 0.125f));
         return __builtin_fmaxf(p, c.p_lo);
     } else {
+        // a in [2^e, 2^(e + 1)) has level e + 1 from the first float that a correctly rounded log2 sends there: the
+        // significand 0x3504EC + kExp1Sig(e + 1), a 4-bit entry per boundary -16 .. 1 (all boundaries of [1e-5, 1e4] that
+        // the clamp to [e_lo, 0] leaves visible; brute force over +-24 ulp of every 2^(k - 0.5))
         const unsigned b = __float_as_uint(a);  // a in [1e-5, 1e4]
-        int k = (int)(b >> 23) - 127 + ((b & 0x7FFFFFu) > 0x3504F3u ? 1 : 0);
+        const int e = (int)(b >> 23) - 127;
+        const int idx = e + 17 < 0 ? 0 : (e + 17 > 17 ? 17 : e + 17);
+        const unsigned sig = 0x3504ECu + (unsigned)(((idx < 16 ? 0x8796a6a4c4c4c4c0ull >> (4 * idx) : 0x87ull >> (4 * (idx - 16)))) & 15u);
+        int k = e + ((b & 0x7FFFFFu) >= sig ? 1 : 0);
         const int lo = (int)c.e_lo;
         k = k < lo ? lo : (k > 0 ? 0 : k);
         return __uint_as_float((unsigned)(k + 127) << 23);
@@ -623,8 +644,10 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     float post = inv_s;
     if constexpr (sizeof(T) == 4) {
         if (exp1_plain_row(c, rmin, rmax)) {  // a property of the row, tested once
-            // the first float of the lowest level e_lo = -(2^(n_bits - 1) - 1): exact up to 3 bits, next(2^(e_lo - 0.5)) beyond
-            const float t_lo = a.n_bits <= 3 ? kExp1From[(1 << (a.n_bits - 1)) - 1] : __uint_as_float(__float_as_uint(c.p_lo * 0x1.6a09e6p-1f) + 1u);
+            // the first float of the lowest level e_lo = -(2^(n_bits - 1) - 1); from 6 bits on e_lo lies below the clamp of
+            // the magnitude at 1e-5, which then ends the live interval
+            const float t_lo = a.n_bits <= 3 ? kExp1From[(1 << (a.n_bits - 1)) - 1]
+                                             : (c.e_lo >= -16.f ? exp1_first_of((int)c.e_lo) : kClipLo);
             auto plain_sums = [&](auto small_tag) {
                 constexpr bool SMALL = decltype(small_tag)::value;
 #pragma unroll

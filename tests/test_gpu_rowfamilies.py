@@ -395,3 +395,76 @@ def test_mixed_bit_grids_on_degenerate_rows(hard):
         out2, scale2, rzp2, _ = F.rowquant_uniform_fwd(x.to(DEV), 0, symmetric, None, None, 0, bits.to(DEV), True)
         assert same(scale2.cpu(), r2.scale) and same(rzp2.cpu(), r2.rzp), ("fixed", symmetric)
         assert same(out2.cpu(), r2.out), ("fixed", symmetric)
+
+
+def _ulp_neighbours(center, n):
+    import numpy as np
+    c = np.float32(center)
+    out, lo, hi = [c], c, c
+    for _ in range(n):
+        lo = np.nextafter(lo, np.float32(-np.inf))
+        hi = np.nextafter(hi, np.float32(np.inf))
+        out += [lo, hi]
+    return [float(v) for v in out]
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_exp2_fp32_is_exact_at_every_level_threshold(bits):
+    """fp32 rows with scale exactly 1 (row maximum = 2 * top), so that |x / s| = |x|: every float within 6 ulp of every
+    level threshold (0.5, 0.75, 1.5 * 2^k up to the top level), both signs.  The kernel's comparisons and exponent-field
+    rule must give what the reference's float arithmetic gives there (torch's CPU log2), bit for bit: no element may
+    differ, near a threshold or not."""
+    top = float(1 << ((1 << (bits - 1)) - 2))
+    probes = []
+    for c in [0.5, 0.75] + [1.5 * 2.0 ** k for k in range(0, 8) if 1.5 * 2.0 ** k < 4 * top]:
+        probes += _ulp_neighbours(c, 6)
+    probes = [p for p in probes if p < 2 * top]
+    row = torch.tensor(probes + [-p for p in probes], dtype=torch.float32)
+    n = 8 * ((row.numel() + 1 + 7) // 8)
+    x = torch.zeros(4, n, dtype=torch.float32)
+    x[:, :row.numel()] = row
+    x[:, -1] = 2 * top                     # the row maximum: s = 2 * top / (2 * top) = 1
+    x[1] = x[1].flip(0).roll(3)            # the same probes in other lanes
+    x[1, -1], x[1, 0] = 2 * top, x[1, -1]
+    x[2] *= -1                             # the extreme on the negative side
+    x[3, :row.numel()] = row * 0.5         # thresholds of a scale that is not 1 ...
+    x[3, -1] = top                         # ... s = 0.5
+    ref = O.exp2_row(x, bits)
+    out, scale = F.rowquant_exp2_fwd(x.to(DEV), bits)
+    assert same(scale.cpu().reshape(-1), ref.scale.reshape(-1))
+    assert torch.equal(out.cpu(), ref.out), (out.cpu() != ref.out).nonzero()[:8]
+    g = torch.ones_like(x)
+    xr = x.clone().requires_grad_(True)
+    (ref_dx,) = torch.autograd.grad((O.exp2_row(xr, bits).out * g).sum(), [xr])
+    dx, _, _ = F.rowquant_exp2_bwd(g.to(DEV), x.to(DEV), bits)
+    ext = (x == x.amax(1, keepdim=True)) | (x == x.amin(1, keepdim=True))  # (receive the routed scale gradient)
+    assert torch.allclose(dx.cpu()[~ext], ref_dx[~ext], rtol=2e-6, atol=0), "alive / dead sets differ at a threshold"
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])  # the entry points take 2 to 4 bits
+def test_exp1_fp32_is_exact_at_every_level_threshold(bits):
+    """The same for the v1 grid (symmetric: scale = row maximum = 1): every float within 6 ulp of 2^(k - 0.5) for every
+    level boundary k = e_lo .. 1, both signs, forward bit for bit and the live set of the backward."""
+    e_lo = -((1 << (bits - 1)) - 1)
+    probes = []
+    for k in range(max(e_lo, -16) - 1, 2):
+        probes += _ulp_neighbours(2.0 ** (k - 0.5), 6)
+    probes = [p for p in probes if p < 1.0]
+    row = torch.tensor(probes + [-p for p in probes], dtype=torch.float32)
+    n = 8 * ((row.numel() + 1 + 7) // 8)
+    x = torch.zeros(3, n, dtype=torch.float32)
+    x[:, :row.numel()] = row
+    x[:, -1] = 1.0
+    x[1] = x[1].flip(0).roll(5)
+    x[1, -1], x[1, 0] = 1.0, x[1, -1]
+    x[2] *= -1
+    ref = O.exp1_row(x, bits, True)
+    out, scale, _mid = F.rowquant_exp1_fwd(x.to(DEV), bits, True)
+    assert same(scale.cpu().reshape(-1), ref.scale.reshape(-1))
+    assert torch.equal(out.cpu(), ref.out), (out.cpu() != ref.out).nonzero()[:8]
+    g = torch.ones_like(x)
+    xr = x.clone().requires_grad_(True)
+    (ref_dx,) = torch.autograd.grad((O.exp1_row(xr, bits, True).out * g).sum(), [xr])
+    dx, _, _ = F.rowquant_exp1_bwd(g.to(DEV), x.to(DEV), bits, True)
+    ext = (x.abs() == x.abs().amax(1, keepdim=True))
+    assert torch.allclose(dx.cpu()[~ext], ref_dx[~ext], rtol=2e-6, atol=0), "live sets differ at a threshold"
