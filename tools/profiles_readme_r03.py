@@ -42,9 +42,9 @@ def main():
     rf = b["roofline"]
     L.append(f"\n`roofline`: dominant family `{rf['family']}` (kernel `{rf['kernel']}`), {rf['achieved']} GB/s = {rf['frac']} of peak, "
              f"{rf['avg_launch_us']} µs per launch by HIP events; `cpu_baseline`: {b['cpu_baseline']['value']} GB/s on "
-             f"{b['cpu_baseline']['cores']} host cores (oracle, `kind: port`).  (The bench line of this file was written before this "
-             "round's `traffic.json` was installed, so its `roofline.traffic` still quotes round 2's constant and says so: "
-             "`traffic_measured_on_this_build: false`.)\n")
+             f"{b['cpu_baseline']['cores']} host cores (oracle, `kind: port`).  `roofline.traffic` = {rf['traffic']} B per launch from the "
+             f"PMC passes of this tag (`traffic_measured_on_this_build: {str(rf['traffic_measured_on_this_build']).lower()}`) against "
+             f"{rf['bytes_per_launch']} B algorithmic.\n")
     L.append("What changed the families: outputs of 16 MiB and more are written non-temporally (their write-back no longer falls on the "
              "next kernels: `act_calib_quant_fwd` 0.49 → 0.58; the row backward pays 1–2 % for it), the activation backward has no partial "
              "planes any more (`k_colbwd_stream` + `k_colbwd_pairs`), the two gathers of a step share one launch.\n")
