@@ -626,8 +626,9 @@ static int launch_gather(int n, const void* const* x, const int* const* idx, voi
     int rows = (int)(65536 / row_bytes);
     if (rows < 1) rows = 1;
     if (rows > 16) rows = 16;
-    // at least ~1024 blocks when the tensors have that many rows: several small tiles per CU stream better than one big one
-    const long long want_rows = R * n / 1024;
+    // at least ~1024 blocks when the tensors have that many rows: several small tiles per CU stream better than one big
+    // one; ~2048 for a batch (two [2048, 4096] fp16 tensors: 22.6 us with 2 rows per block against 23.5 with 4, 25.3 with 1)
+    const long long want_rows = R * n / (n >= 2 ? 2048 : 1024);
     if (rows > want_rows) rows = (int)(want_rows < 1 ? 1 : want_rows);
     if (rows > R) rows = (int)R;
     const size_t lds = (size_t)rows * row_bytes;
