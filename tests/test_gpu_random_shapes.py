@@ -2,6 +2,7 @@
 oracle: widths that are not a multiple of the 16-byte pack (the scalar tiles), one-row and one-column matrices, every
 tile of the dispatch tables, groups that do not divide the row, cluster layouts with leftovers.  Forward results must be
 the oracle's bits (the kernels take activated clip factors: the oracle's own sigmoid values are handed over)."""
+import os
 import random
 
 import pytest
@@ -18,8 +19,12 @@ DEV = "cuda:0"
 WIDTHS = [1, 3, 8, 17, 64, 100, 255, 256, 520, 768, 1000, 1024, 1028, 2048, 2052, 3072, 4100, 5120, 8192, 11008, 13824]
 
 
+# other shapes and dtypes on request (a soak run over several offsets: MIQ_TEST_SEED_OFFSET=1 pytest tests/test_gpu_random_shapes.py)
+SEED_OFFSET = int(os.environ.get("MIQ_TEST_SEED_OFFSET", "0"))
+
+
 def _cases(n, seed):
-    rnd = random.Random(seed)
+    rnd = random.Random(seed + SEED_OFFSET)
     out = []
     for i in range(n):
         I = rnd.choice(WIDTHS)
@@ -54,7 +59,7 @@ def test_uniform_forward_random_case(i, Orows, I, dt, bits, sym, lwc, group):
 
 
 def _act_cases(n, seed):
-    rnd = random.Random(seed)
+    rnd = random.Random(seed + SEED_OFFSET)
     out = []
     for i in range(n):
         C = rnd.choice([8, 64, 100, 256, 520, 1000, 1024, 2048, 2752, 4096, 5120])
@@ -88,7 +93,7 @@ def test_activation_forward_random_case(i, R, C, dt, bits, counts):
 
 
 def _row_cases(n, seed):
-    rnd = random.Random(seed)
+    rnd = random.Random(seed + SEED_OFFSET)
     out = []
     for i in range(n):
         I = rnd.choice(WIDTHS[2:])
