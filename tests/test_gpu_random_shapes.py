@@ -92,6 +92,38 @@ def test_activation_forward_random_case(i, R, C, dt, bits, counts):
     assert torch.equal(codes[0].cpu().to(torch.int32), torch.nan_to_num(ref_codes, nan=0.0).to(torch.int32))
 
 
+@pytest.mark.parametrize("i,R,C,dt,bits,counts", _act_cases(28, 99))
+def test_activation_backward_random_case(i, R, C, dt, bits, counts):
+    """The input gradient of the calibrating activation quantizer (two-launch form where the layout allows it, the
+    four-kernel form otherwise) against the oracle's autograd: elements away from the cluster extremes to rounding, the
+    few that receive a share of the scale gradient to the tolerance of another summation order.  Every other case has
+    ReLU-style mass ties at its minimum."""
+    from helpers import rel_err
+    from miq import synth as S
+    dtype = DT[dt]
+    layout = F.ClusterLayout.get(counts, C, DEV)
+    kw = dict(method="per_cluster" if counts else "per_tensor", metric="minmax", cluster_dim=1 if counts else None,
+              cluster_counts=counts)
+    x = S.activation((R, C), 3100 + i, dtype)
+    if i % 2:
+        x = torch.relu(x)
+    g = S.grad_like(x, 3200 + i)
+    xd, gd = x.to(DEV), g.to(DEV)
+    _outs, _codes, vecs = F.act_fresh_quant_fwd([xd], bits, layout)
+    dx = F.act_fresh_quant_bwd([gd], [xd], vecs, bits, layout)[0].cpu()
+    xr = x.clone().requires_grad_(True)
+    ref, _ = O.act_forward(xr, O.ActState(), bits, "calibration", **kw)
+    (ref_dx,) = torch.autograd.grad((ref.float() * g.float()).sum(), [xr])
+    ok = torch.isfinite(ref_dx)
+    cmin, cmax = vecs[0][0].cpu(), vecs[0][1].cpu()
+    routed = (x == cmax) | (x == cmin)
+    z = torch.zeros_like(ref_dx)
+    tight = 1e-5 if dtype == torch.float32 else 2e-2
+    for sel, tol in ((ok & ~routed, tight), (ok & routed, max(tight, 5e-3))):
+        err = rel_err(torch.where(sel, dx, z), torch.where(sel, ref_dx, z))
+        assert err <= tol, (i, err, tol)
+
+
 def _row_cases(n, seed):
     rnd = random.Random(seed + SEED_OFFSET)
     out = []
