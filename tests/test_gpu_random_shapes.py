@@ -119,7 +119,10 @@ def test_activation_backward_random_case(i, R, C, dt, bits, counts):
     routed = (x == cmax) | (x == cmin)
     z = torch.zeros_like(ref_dx)
     tight = 1e-5 if dtype == torch.float32 else 2e-2
-    for sel, tol in ((ok & ~routed, tight), (ok & routed, max(tight, 5e-3))):
+    # routed elements carry the scale gradient, a sum over the whole cluster: the reference rounds every product to fp16
+    # before it sums them (terms of both signs: up to a million per cluster here), the kernel accumulates in fp32
+    loose = 5e-3 if dtype == torch.float32 else 5e-2
+    for sel, tol in ((ok & ~routed, tight), (ok & routed, loose)):
         err = rel_err(torch.where(sel, dx, z), torch.where(sel, ref_dx, z))
         assert err <= tol, (i, err, tol)
 
