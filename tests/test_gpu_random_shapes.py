@@ -223,6 +223,37 @@ def test_mixed_bit_and_let_forward_random_case(i, Orows, I, dt, bits, sym, lwc):
             assert same(scale.cpu(), res.scale) and same(rzp.cpu(), res.rzp) and same(out.cpu(), res.out), ("let", mode)
 
 
+@pytest.mark.parametrize("i,Orows,I,dt,bits,sym,lwc", [c for c in _row_cases(48, 515) if c[3] == "f32" and c[2] % 4 == 0][:16])
+def test_mixed_bit_backward_random_case(i, Orows, I, dt, bits, sym, lwc):
+    """Gradients of the learnable mixed-bit quantizer (input, bit-width, clip factors) in its soft and hard phase against
+    the oracle's autograd; rows with a whole-number bit-width, every row in the hard phase, take the single-grid path."""
+    from test_gpu_rowfamilies import chain
+    x = synth.weight(Orows, I, 6100 + i)
+    w = synth.grad_like(x, 6200 + i)
+    up = low = su = sl = None
+    ps = []
+    if lwc:
+        up, low = synth.lwc_factors(Orows, 7100 + i)
+        su, sl = torch.sigmoid(up).to(DEV), torch.sigmoid(low).to(DEV)
+        ps = [up.clone().requires_grad_(True), low.clone().requires_grad_(True)]
+    nb = synth.mix_bits(Orows, 3.0, 8100 + i)
+    nb[::3] = nb[::3].round()  # whole-number rows in the soft phase too
+    floor = 1e-6 * (w.abs() * x.abs()).sum(1, keepdim=True).norm()
+
+    def close(a, ref, tol):
+        return (a.float().cpu() - ref.float()).norm() <= tol * ref.float().norm() + floor
+    for hard in (False, True):
+        xg, ng = x.clone().requires_grad_(True), nb.clone().requires_grad_(True)
+        r = O.mix_row(xg, ng, sym, *(ps if lwc else (None, None)), None, hard, 0.0)
+        g = torch.autograd.grad((r.out * w).sum(), [xg, ng] + ps, allow_unused=True)
+        dx, d_su, d_sl, d_n = F.rowquant_mix_bwd(w.to(DEV), x.to(DEV), nb.reshape(-1).to(DEV), sym, su, sl, 0, hard, 0.0)
+        assert close(dx, g[0], 4e-5), ("dx", hard)
+        if g[1] is not None:
+            assert close(d_n.reshape(-1, 1), g[1], 5e-4), ("d_nbits", hard)
+        if lwc:
+            assert close(chain(d_su, su), g[2], 5e-4) and close(chain(d_sl, sl), g[3], 5e-4), ("clip factors", hard)
+
+
 @pytest.mark.parametrize("I", [2048, 4096, 8192, 11008, 13824, 28672])
 @pytest.mark.parametrize("dt", ["f32", "f16"])
 def test_exponent_grids_backward_at_every_tile(I, dt):
