@@ -455,7 +455,7 @@ k_colquant_slots(SlabPtrs xs, SlotMap sm, u64* ws_base, long long ws_stride, Sla
     Pack<T, VEC> first[DEPTH];
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u)
-        if (r + 4 * u < r1) first[u] = ld_pack<T, VEC>(x + (r + 4 * u) * C + col0);
+        if (r + 4 * u < r1) first[u] = ld_pack_nt<T, VEC>(x + (r + 4 * u) * C + col0);
     float s[NP], z[NP], rs[NP];
     bool ok = true;
     {
@@ -501,11 +501,11 @@ k_colquant_slots(SlabPtrs xs, SlotMap sm, u64* ws_base, long long ws_stride, Sla
         for (; r + (DEPTH - 1) * 4 < r1; r += DEPTH * 4) {
             Pack<T, VEC> a[DEPTH];
 #pragma unroll
-            for (int u = 0; u < DEPTH; ++u) a[u] = ld_pack<T, VEC>(x + (r + 4 * u) * C + col0);
+            for (int u = 0; u < DEPTH; ++u) a[u] = ld_pack_nt<T, VEC>(x + (r + 4 * u) * C + col0);
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u) body(a[u], r + 4 * u);
         }
-        for (; r < r1; r += 4) body(ld_pack<T, VEC>(x + r * C + col0), r);
+        for (; r < r1; r += 4) body(ld_pack_nt<T, VEC>(x + r * C + col0), r);
     };
     if (sizeof(T) == 4 || exact_int) stream_rows(std::true_type{});
     else stream_rows(std::false_type{});

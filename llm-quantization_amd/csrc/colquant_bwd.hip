@@ -131,8 +131,8 @@ k_colbwd_stream(BwdSlabs slabs, long long R, int C, int rows_per_chunk, float qm
         for (int u = 0; u < UNR; ++u) {
             const long long rr = r + 4 * u;
             if (rr < r1) {
-                pa[u] = ld_pack<T, VEC>(x + rr * C + col0);
-                pb[u] = ld_pack<T, VEC>(g + rr * C + col0);
+                pa[u] = ld_pack_nt<T, VEC>(x + rr * C + col0);
+                pb[u] = ld_pack_nt<T, VEC>(g + rr * C + col0);
             }
         }
     };

@@ -156,7 +156,7 @@ __device__ __forceinline__ void exp2_fwd_row(const ExpArgs<T>& a, const RowGeom&
     int len;
     row_span(geo, row, base, len);
     RowTile<T, VEC, TEAM, NV> x;
-    x.load(a.x + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const Exp2Ctx c = exp2_ctx<T>(a, row, rmin, rmax);
@@ -232,8 +232,8 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
     int len;
     row_span(geo, row, base, len);
     RowTile<T, VEC, TEAM, NV> x, g;
-    x.load(a.x + base, len, lane);
-    g.load(gout + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
+    g.load_nt(gout + base, len, lane);
     const bool padded = len < geo.g;
     float rmin, rmax;
     // fp32: the elements at the row extremes (rarely in more than two lanes of a row) are counted and corrected only by
@@ -542,7 +542,7 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     int len;
     row_span(geo, row, base, len);
     RowTile<T, VEC, TEAM, NV> x;
-    x.load(a.x + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const Exp1Ctx c = exp1_ctx<T>(a, row, rmin, rmax);
@@ -597,8 +597,8 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     int len;
     row_span(geo, row, base, len);
     RowTile<T, VEC, TEAM, NV> x, g;
-    x.load(a.x + base, len, lane);
-    g.load(gout + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
+    g.load_nt(gout + base, len, lane);
     const bool padded = len < geo.g;
     float rmin, rmax;
     // fp32: the elements at the row extremes are counted and corrected only by the lanes that hold them (k_exp2_bwd)

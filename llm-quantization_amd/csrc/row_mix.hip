@@ -112,7 +112,7 @@ __device__ __forceinline__ void mix_fwd_row(const MixArgs& a, const RowGeom& geo
     int len;
     row_span(geo, row, base, len);
     RowTile<float, VEC, TEAM, NV> x;
-    x.load(a.x + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
     float rmin, rmax;
     row_minmax(x, len < geo.g, lds, rmin, rmax);
     const MixCtx c = mix_ctx(a, row, rmin, rmax);
@@ -186,8 +186,8 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
     int len;
     row_span(geo, row, base, len);
     RowTile<float, VEC, TEAM, NV> x, g;
-    x.load(a.x + base, len, lane);
-    g.load(gout + base, len, lane);
+    x.load_nt(a.x + base, len, lane);
+    g.load_nt(gout + base, len, lane);
     const bool padded = len < geo.g;
     float rmin, rmax;
     bool at_extreme;  // one of this lane's elements equals a row extreme (rarely true in more than two lanes of a row)
