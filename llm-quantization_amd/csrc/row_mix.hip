@@ -69,7 +69,18 @@ __device__ __forceinline__ MixCtx mix_ctx(const MixArgs& a, long long row, float
     c.rng = c.clip.xmax - c.clip.xmin;
     c.amax = nmax(fabsf(c.clip.xmax), fabsf(c.clip.xmin));
     make_grid(c.lo, nl, lp, c, a.symmetric);
-    make_grid(c.hi, nh, hp, c, a.symmetric);
+    // a whole number of bits (every row of the hard phase): floor and ceiling are the same grid, so the second one is
+    // the first with weight 0 (field by field: assigning the struct under the branch puts it into scratch memory)
+    const bool whole = hp == 0.f;
+    if (!whole) make_grid(c.hi, nh, hp, c, a.symmetric);
+    c.hi.b = whole ? c.lo.b : c.hi.b;
+    c.hi.Q = whole ? c.lo.Q : c.hi.Q;
+    c.hi.H = whole ? c.lo.H : c.hi.H;
+    c.hi.s = whole ? c.lo.s : c.hi.s;
+    c.hi.s_raw = whole ? c.lo.s_raw : c.hi.s_raw;
+    c.hi.z = whole ? c.lo.z : c.hi.z;
+    c.hi.rs = whole ? c.lo.rs : c.hi.rs;
+    c.hi.w = hp;
     return c;
 }
 
@@ -87,8 +98,10 @@ __device__ __forceinline__ float plain_quotient(float xv, const Grid& gr) {
     return __builtin_fmaf(__builtin_fmaf(-q0, gr.s, xv), gr.rs, q0);
 }
 __device__ __forceinline__ float plain_fq(float xv, const Grid& gr) {
+    // a finite quotient: (rint(q) - q) + q, the straight-through form of the reference, is rint(q) itself (the
+    // difference is exact, and so is adding q back)
     const float q = plain_quotient(xv, gr);
-    const float xi = ((rintf(q) - q) + q) + gr.z;
+    const float xi = rintf(q) + gr.z;
     return (__builtin_amdgcn_fmed3f(xi, 0.f, gr.Q) - gr.z) * gr.s;
 }
 
@@ -260,26 +273,29 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
         if (rmax == 0.f) acc[4] += npad;
         if (rmin == 0.f) acc[5] += npad;
     }
-    float d_xmax, d_xmin, d_n = 0.f;
-    auto live = [](const Grid& gr) { return gr.s_raw >= kClipLo && gr.s_raw <= kClipHi; };
-    if (a.symmetric) {
-        const float dS_l = acc[0], dS_h = acc[1];
-        d_n += (dS_l * (-c.amax / (c.lo.H * c.lo.H))) * (kLn2m * exp2f(c.lo.b - 1.f));
-        d_n += (dS_h * (-c.amax / (c.hi.H * c.hi.H))) * (kLn2m * exp2f(c.hi.b - 1.f));
-        d_n += acc[2] * (kLn2m * exp2f(c.lo.b)) + acc[3] * (kLn2m * exp2f(c.hi.b));
-        route_absmax(dS_l / c.lo.H + dS_h / c.hi.H, c.clip, d_xmax, d_xmin);
-    } else {
-        const float dS_l = live(c.lo) ? acc[0] : 0.f, dS_h = live(c.hi) ? acc[1] : 0.f;
-        const float dQ_l = acc[2] + dS_l * (-c.rng / (c.lo.Q * c.lo.Q));
-        const float dQ_h = acc[3] + dS_h * (-c.rng / (c.hi.Q * c.hi.Q));
-        d_n = dQ_l * (kLn2m * exp2f(c.lo.b)) + dQ_h * (kLn2m * exp2f(c.hi.b));
-        const float d_rng = dS_l / c.lo.Q + dS_h / c.hi.Q;
-        d_xmax = d_rng;
-        d_xmin = -d_rng;
-    }
-    if (lane == 0) {
-        if (d_nbits) d_nbits[row] = d_n;
-        if (a.up) write_lwc_grads<float>(d_up, d_low, row, rmin, rmax, d_xmax, d_xmin);
+    float d_xmax = 0.f, d_xmin = 0.f;
+    if (lane == 0 || at_extreme) {  // the other lanes (most waves of a team as a whole) need none of the row's gradients
+        float d_n = 0.f;
+        auto live = [](const Grid& gr) { return gr.s_raw >= kClipLo && gr.s_raw <= kClipHi; };
+        if (a.symmetric) {
+            const float dS_l = acc[0], dS_h = acc[1];
+            d_n += (dS_l * (-c.amax / (c.lo.H * c.lo.H))) * (kLn2m * exp2f(c.lo.b - 1.f));
+            d_n += (dS_h * (-c.amax / (c.hi.H * c.hi.H))) * (kLn2m * exp2f(c.hi.b - 1.f));
+            d_n += acc[2] * (kLn2m * exp2f(c.lo.b)) + acc[3] * (kLn2m * exp2f(c.hi.b));
+            route_absmax(dS_l / c.lo.H + dS_h / c.hi.H, c.clip, d_xmax, d_xmin);
+        } else {
+            const float dS_l = live(c.lo) ? acc[0] : 0.f, dS_h = live(c.hi) ? acc[1] : 0.f;
+            const float dQ_l = acc[2] + dS_l * (-c.rng / (c.lo.Q * c.lo.Q));
+            const float dQ_h = acc[3] + dS_h * (-c.rng / (c.hi.Q * c.hi.Q));
+            d_n = dQ_l * (kLn2m * exp2f(c.lo.b)) + dQ_h * (kLn2m * exp2f(c.hi.b));
+            const float d_rng = dS_l / c.lo.Q + dS_h / c.hi.Q;
+            d_xmax = d_rng;
+            d_xmin = -d_rng;
+        }
+        if (lane == 0) {
+            if (d_nbits) d_nbits[row] = d_n;
+            if (a.up) write_lwc_grads<float>(d_up, d_low, row, rmin, rmax, d_xmax, d_xmin);
+        }
     }
     if (dx) {
         if (at_extreme) {
