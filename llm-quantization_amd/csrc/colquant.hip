@@ -203,13 +203,27 @@ __global__ void __launch_bounds__(256) k_cluster_scale(ScaleArgs<T> a) {
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __restrict__ rzp,
-               T* __restrict__ out, uint8_t* __restrict__ codes, long long R, int C, int rows_per_chunk, float qmax) {
+               T* __restrict__ out, uint8_t* __restrict__ codes, long long R, int C, int rows_per_chunk, float qmax,
+               int stream_out) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long col0 = ((long long)blockIdx.x * 64 + lane) * VEC;
     if (col0 >= C) return;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
+    // x is read for the last time here (its statistics, if any were taken, came from an earlier kernel).  fp32: the first
+    // batch of rows is requested before the parameters, so that the two round trips overlap, and a wave of a 32-row
+    // chunk has all of its rows in flight at once ([2048, 4096]: 17.5 -> 14.7 us).  fp16 packs (twice the registers
+    // per row) keep four rows per batch behind the parameters: the early batch costs a wave per SIMD (10.7 -> 12.7 us).
+    constexpr bool EARLY = sizeof(T) == 4;
+    constexpr int DEPTH = EARLY ? 8 : 4;
+    long long r = r0 + w;
+    Pack<T, VEC> first[DEPTH];
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if (r + 4 * u < r1) first[u] = ld_pack_nt<T, VEC>(x + (r + 4 * u) * C + col0);
+    }
     float s[VEC], z[VEC], rs[VEC];
     bool ok = true;
     {
@@ -228,7 +242,7 @@ k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __
     // become a scalar branch around every fp16 re-rounding
     auto stream_rows = [&](auto exact_tag) {
         constexpr bool EX = decltype(exact_tag)::value;
-        auto body = [&](const Pack<T, VEC>& a, long long r) {
+        auto body = [&](const Pack<T, VEC>& a, long long rr) {
             Pack<T, VEC> o;
             Pack<uint8_t, VEC> cd;
 #pragma unroll
@@ -238,23 +252,23 @@ k_colquant_fwd(const T* __restrict__ x, const T* __restrict__ scale, const T* __
                 o.e[e] = from_f<T>(affine_dequant<T>(xc, s[e], z[e], EX));
                 if (codes) cd.e[e] = (xc == xc) ? (uint8_t)xc : (uint8_t)0;
             }
-            st_pack<T, VEC>(out + r * C + col0, o);
-            if (codes) st_pack<uint8_t, VEC>(codes + r * C + col0, cd);
+            st_out<T, VEC>(out + rr * C + col0, o, stream_out);
+            if (codes) st_out<uint8_t, VEC>(codes + rr * C + col0, cd, stream_out);
         };
-        long long r = r0 + w;
-        for (; r + 12 < r1; r += 16) {
-            Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
-            Pack<T, VEC> b = ld_pack<T, VEC>(x + (r + 4) * C + col0);
-            Pack<T, VEC> c = ld_pack<T, VEC>(x + (r + 8) * C + col0);
-            Pack<T, VEC> d = ld_pack<T, VEC>(x + (r + 12) * C + col0);
-            body(a, r);
-            body(b, r + 4);
-            body(c, r + 8);
-            body(d, r + 12);
+        if constexpr (EARLY) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u)
+                if (r + 4 * u < r1) body(first[u], r + 4 * u);
+            r += 4 * DEPTH;
         }
-        for (; r < r1; r += 4) {
-            Pack<T, VEC> a = ld_pack<T, VEC>(x + r * C + col0);
-            body(a, r);
+        // whole and partial batches alike (the bounds are wave-uniform): a tail row at a time would be a round trip each
+        for (; r < r1; r += 4 * DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u)
+                if (r + 4 * u < r1) first[u] = ld_pack_nt<T, VEC>(x + (r + 4 * u) * C + col0);
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u)
+                if (r + 4 * u < r1) body(first[u], r + 4 * u);
         }
     };
     if (sizeof(T) == 4 || exact_int) stream_rows(std::true_type{});
@@ -591,18 +605,19 @@ static int launch_colquant_fwd(const void* x, const void* scale, const void* rzp
     const bool vec_ok = (C % N == 0) && aligned16(x) && aligned16(out) && aligned16(scale) && aligned16(rzp) &&
                         (!codes || (reinterpret_cast<uintptr_t>(codes) % N) == 0);
     const float qmax = (float)((1 << n_bits) - 1);
+    const int so = stream_out_of(R * C * (long long)sizeof(T));
     if (vec_ok) {
         const int tiles = (int)((C / N + 63) / 64);
         const int nchunk = pick_chunks(R, tiles);
         const int rpc = (int)((R + nchunk - 1) / nchunk);
         hipLaunchKernelGGL((k_colquant_fwd<T, N>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x,
-                           (const T*)scale, (const T*)rzp, (T*)out, (uint8_t*)codes, R, (int)C, rpc, qmax);
+                           (const T*)scale, (const T*)rzp, (T*)out, (uint8_t*)codes, R, (int)C, rpc, qmax, so);
     } else {
         const int tiles = (int)((C + 63) / 64);
         const int nchunk = pick_chunks(R, tiles);
         const int rpc = (int)((R + nchunk - 1) / nchunk);
         hipLaunchKernelGGL((k_colquant_fwd<T, 1>), dim3(tiles, nchunk), dim3(256), 0, stream, (const T*)x,
-                           (const T*)scale, (const T*)rzp, (T*)out, (uint8_t*)codes, R, (int)C, rpc, qmax);
+                           (const T*)scale, (const T*)rzp, (T*)out, (uint8_t*)codes, R, (int)C, rpc, qmax, so);
     }
     MIQ_CHECK_LAUNCH("miq_colquant_fwd");
     return 0;
