@@ -79,13 +79,19 @@ FAMILY_KERNEL = {"rowquant_fwd": "k_uniform_fwd_batch", "rowquant_bwd": "k_unifo
 
 
 class Segments:
-    """HIP-event brackets around kernel families, recorded on the stream the kernels run on."""
+    """HIP-event brackets around kernel families, recorded on the stream the kernels run on.  An event record is not free
+    on this GPU: about 5 us of stream time each (a step of six families bracketed one by one ran 1.14 ms, the same six
+    graphs without events 1.06 ms; an event-record NODE inside one graph of the whole step costs the same, and torch
+    refuses external events on ROCm anyway).  So the timed region brackets only the dominant family (`only`), and the
+    table of all families comes from an instrumented pass of the same steps in front of it (`boundaries`: one event at
+    each family boundary, shared by the two neighbours)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.ev = {}
+        self.only = only
 
     def run(self, name, fn, timed):
-        if not timed:
+        if not timed or (self.only is not None and name not in self.only):
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -93,6 +99,15 @@ class Segments:
         b.record()
         self.ev.setdefault(name, []).append((a, b))
         return r
+
+    def boundaries(self, fams):
+        """One pass over `fams` with an event at every boundary."""
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(fams) + 1)]
+        marks[0].record()
+        for i, (name, fn) in enumerate(fams):
+            fn()
+            marks[i + 1].record()
+            self.ev.setdefault(name, []).append((marks[i], marks[i + 1]))
 
     def totals_ms(self):
         return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.ev.items()}
@@ -207,9 +222,12 @@ class Workload:
         torch.cuda.synchronize()
         return _capture_all(fams, side)
 
-    def step(self, fams, seg: Segments, timed: bool, world: int):
-        for name, fn in fams:
-            seg.run(name, fn, timed)
+    def step(self, fams, seg: Segments, timed: bool, world: int, boundaries: bool = False):
+        if boundaries:
+            seg.boundaries(fams)
+        else:
+            for name, fn in fams:
+                seg.run(name, fn, timed)
         if world > 1:
             if os.environ.get("MIQ_BENCH_ONE_GPU") == "1":  # rehearsal: gloo reduces a host copy
                 host = self.flat.cpu()
@@ -335,10 +353,18 @@ def run_c4(args, world, rank, dev, rehearsal, barrier):
     from miq.dist import DPContext
     ctx = DPContext.from_env()
     wl = C4Workload(dev, ctx, rehearsal)
-    seg = Segments()
     fams = wl.families() if args.eager else wl.capture()
+    idle = Segments()
     for _ in range(args.warmup):
-        wl.step(fams, seg, False)
+        wl.step(fams, idle, False)
+    # every family (and the all-gather) bracketed, outside the timed region; the timed region brackets the dominant one
+    seg_all = Segments()
+    for _ in range(args.steps):
+        wl.step(fams, seg_all, True)
+    torch.cuda.synchronize()
+    totals_all = seg_all.totals_ms()
+    dom = max(wl.bytes(), key=lambda k: totals_all[k])
+    seg = Segments(only={dom})
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -351,20 +377,19 @@ def run_c4(args, world, rank, dev, rehearsal, barrier):
         dt = float(t.item())
     if rank != 0:
         return
-    totals = seg.totals_ms()
+    totals = seg.totals_ms()  # the timed region: the dominant family only
     by = wl.bytes()
     step_bytes = sum(by.values())
     # rank 0's own kernels move 1/world of the layer: per-rank GB/s against this GPU's HBM peak
-    fam = {k: {"kernel": C4_KERNEL[k], "GBps_per_rank": round(by[k] / world * args.steps / (totals[k] * 1e-3) / 1e9, 1),
-               "frac_hbm_peak": round(by[k] / world * args.steps / (totals[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": wl.launches(k)} for k in by}
+    fam = {k: {"kernel": C4_KERNEL[k], "GBps_per_rank": round(by[k] / world * args.steps / (totals_all[k] * 1e-3) / 1e9, 1),
+               "frac_hbm_peak": round(by[k] / world * args.steps / (totals_all[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "ms_per_step": round(totals_all[k] / args.steps, 4), "launches_per_step": wl.launches(k)} for k in by}
     if world > 1:
-        ms = totals["all_gather"] / args.steps
+        ms = totals_all["all_gather"] / args.steps
         fam["all_gather"] = {"kernel": C4_KERNEL["all_gather"], "ms_per_step": round(ms, 4),
                              "GBps_into_each_rank": round(wl.gather_bytes_in() / (ms * 1e-3) / 1e9, 1),
                              "collectives_per_step": len(L13),
                              "transport": "gloo over host copies (one-GPU rehearsal)" if rehearsal else "RCCL over xGMI"}
-    dom = max(by, key=lambda k: totals[k])
     achieved = by[dom] / world * args.steps / (totals[dom] * 1e-3) / 1e9
     out = {
         "metric": "fake-quant GB/s (% HBM peak) + OmniQuant block-calib s/layer, Llama-2-7B",
@@ -394,6 +419,8 @@ def run_c4(args, world, rank, dev, rehearsal, barrier):
                      "bytes_per_launch": by[dom] // world // wl.launches(dom),
                      "avg_launch_us": round(totals[dom] * 1e3 / (wl.launches(dom) * args.steps), 2)},
         "families": fam,
+        "families_timing": f"instrumented pass of {args.steps} steps in front of the timed region (HIP events around every family, "
+                           f"about 5 us of stream time per event record); the timed region brackets only {dom}",
     }
     print(json.dumps(out))
 
@@ -404,12 +431,13 @@ C34_KERNEL = {"exp2": ("k_exp2_fwd_batch", "k_exp2_bwd_batch"), "exp1": ("k_exp1
               "mix2": ("k_uniform_fwd_bits_batch", "k_uniform_bwd_bits_batch")}
 
 
-def families_c3_c4(dev, replays=20):
+def families_c3_c4(dev, replays=20, rounds=3):
     """The exponent (v2 and v1, W3, Llama-2-7B matrices) and mixed-bit (learnable soft / hard, fixed; Llama-2-13B
     matrices) weight quantizers, forward and backward with input gradient, fp32 with learnable clipping: the operator
     families the timed step does not contain.  One HIP graph per family and direction over the seven matrices of a
-    layer (0.8 / 1.3 GB per operand: several times the 256 MiB Infinity Cache), timed with HIP events around each of
-    `replays` replays; the median replay gives GB/s of algorithmic bytes (forward 2ns, backward 3ns)."""
+    layer (0.8 / 1.3 GB per operand: several times the 256 MiB Infinity Cache, so back-to-back replays find nothing
+    cached), timed with one pair of HIP events around `replays` replays, `rounds` times; the median round gives GB/s of
+    algorithmic bytes (forward 2ns, backward 3ns)."""
     out = {}
     side = torch.cuda.Stream(device=dev)
 
@@ -425,14 +453,15 @@ def families_c3_c4(dev, replays=20):
         ts = []
         with torch.cuda.stream(side):
             g.replay()
-            for _ in range(replays):
+            for _ in range(rounds):  # `replays` replays between one pair of events: the event records' own time is spread thin
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                g.replay()
+                for _ in range(replays):
+                    g.replay()
                 b.record()
                 ts.append((a, b))
         side.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in ts)
+        ms = sorted(a.elapsed_time(b) / replays for a, b in ts)
         return ms[len(ms) // 2] * 1e-3
 
     def layer(shapes, seed):
@@ -453,7 +482,7 @@ def families_c3_c4(dev, replays=20):
             gbs = mult * nbytes / t / 1e9
             out[f"{name}_{tag}"] = {"kernel": kern, "shapes": shapes_tag, "GBps": round(gbs, 1),
                                     "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "launches": launches,
-                                    "us_per_launch": round(t / launches * 1e6, 2), "replays": replays}
+                                    "us_per_launch": round(t / launches * 1e6, 2), "replays": replays, "rounds": rounds}
 
     # exponent quantizers, W3, the seven Llama-2-7B matrices
     xs, gs, ups, lows, groups, nbytes = layer(L7, 700)
@@ -681,11 +710,38 @@ def main():
         return
 
     wl = Workload(dev, seed=2 + 1000 * rank)
-    seg = Segments()
-
     fams = wl.families() if args.eager else wl.capture()
+    idle = Segments()
     for _ in range(args.warmup):
-        wl.step(fams, seg, False, world)
+        wl.step(fams, idle, False, world)
+    # instrumented pass (outside the timed region): every family between two boundary events -> the family table, and
+    # which family is the dominant one
+    seg_all = Segments()
+    for _ in range(args.steps):
+        wl.step(fams, seg_all, True, world, boundaries=True)
+    torch.cuda.synchronize()
+    totals_all = seg_all.totals_ms()
+    # the dominant KERNEL: the row families are one kernel each (two launches, one per row width), the activation
+    # families chains of two kernels per call whose streaming kernels each take less than k_uniform_bwd_batch does
+    # (profiles/: rocprofv3 kernel trace of this command)
+    kernels_in = {"act_calib_quant_fwd": 2, "act_bwd": 2}
+    dom = max(totals_all, key=lambda k: totals_all[k] / kernels_in.get(k, 1))
+    # what the step loses when a family is left out: the sequence of all families against the sequence without it, each
+    # between ONE pair of events over all steps (no event inside the sequence; the launch gaps of the family count)
+    def sequence_ms(skip):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(args.steps + 2):
+            if i == 2:
+                a.record()
+            for name, fn in fams:
+                if name != skip:
+                    fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / args.steps
+    whole_ms = sequence_ms(None)
+    marginal_ms = {name: whole_ms - sequence_ms(name) for name, _fn in fams}
+    seg = Segments(only={dom})
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -716,16 +772,13 @@ def main():
         """Rank 0's result line."""
         by = by_local
         step_bytes = sum(by.values())
-        totals = totals_local
-        fam = {k: {"kernel": FAMILY_KERNEL[k], "GBps": round(by[k] * args.steps / (totals[k] * 1e-3) / 1e9, 1),
-                   "frac_hbm_peak": round(by[k] * args.steps / (totals[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                   "ms_per_step": round(totals[k] / args.steps, 4), "launches_per_step": launches[k]}
+        totals = totals_local  # the timed region: the dominant family only
+        fam = {k: {"kernel": FAMILY_KERNEL[k], "GBps": round(by[k] * args.steps / (totals_all[k] * 1e-3) / 1e9, 1),
+                   "frac_hbm_peak": round(by[k] * args.steps / (totals_all[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "ms_per_step": round(totals_all[k] / args.steps, 4), "launches_per_step": launches[k],
+                   "ms_left_out": round(marginal_ms[k], 4),
+                   "frac_hbm_peak_left_out": round(by[k] / (marginal_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if marginal_ms[k] > 0 else None}
                for k in by}
-        # the dominant KERNEL: the row families are one kernel each (two launches, one per row width), the activation
-        # families chains of two / three kernels per call whose streaming kernels each take less than
-        # k_uniform_bwd_batch does (profiles/: rocprofv3 kernel trace of this command)
-        kernels_in = {"act_calib_quant_fwd": 2, "act_bwd": 2}
-        dom = max(totals, key=lambda k: totals[k] / kernels_in.get(k, 1))
         n_launch = launches[dom] * args.steps
         achieved = by[dom] * args.steps / (totals[dom] * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled, WRITE_SIZE as read) of a separate rocprofv3 run of
@@ -767,6 +820,13 @@ def main():
                          "bytes_per_launch": by[dom] // launches[dom],
                          "avg_launch_us": round(totals[dom] * 1e3 / n_launch, 2)},
             "families": fam,
+            "families_timing": f"instrumented pass of {args.steps} steps in front of the timed region: the same graphs in the same "
+                               "order with one HIP event at each of the 7 family boundaries (an event record takes about 5 us "
+                               "of stream time, which every family figure includes once); the timed region itself brackets "
+                               f"only {dom}, from which `roofline` is computed.  ms_left_out / frac_hbm_peak_left_out: the whole "
+                               f"sequence ({whole_ms:.4f} ms between one pair of events, no event inside) minus the sequence "
+                               "without that family, i.e. what the family costs the step with its launch gaps and without "
+                               "any event record",
         }
         if fam34 is not None:
             out["families_c3_c4"] = fam34

@@ -538,7 +538,7 @@ struct GatherSlabs {
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-k_gather(GatherSlabs slabs, long long R, int C, int rows_per_block) {
+k_gather(GatherSlabs slabs, long long R, int C, int rows_per_block, int stream_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     T* tile = reinterpret_cast<T*>(smem);  // [rows_per_block][C]
     const T* __restrict__ x = static_cast<const T*>(slabs.x[blockIdx.y]);
@@ -562,7 +562,7 @@ k_gather(GatherSlabs slabs, long long R, int C, int rows_per_block) {
             Pack<T, VEC> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o.e[e] = tile[(long long)rr * C + id[e]];
-            st_pack<T, VEC>(dst + (long long)rr * C + (long long)p * VEC, o);
+            st_out<T, VEC>(dst + (long long)rr * C + (long long)p * VEC, o, stream_out);
         }
     }
 }
@@ -648,12 +648,13 @@ static int launch_gather(int n, const void* const* x, const int* const* idx, voi
     if (rows > R) rows = (int)R;
     const size_t lds = (size_t)rows * row_bytes;
     const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)n);
+    const int so = stream_out_of(R * row_bytes * n);
     if (vec_ok) {
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_gather<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gather<T, N>), grid, dim3(256), lds, stream, slabs, R, (int)C, rows);
+        hipLaunchKernelGGL((k_gather<T, N>), grid, dim3(256), lds, stream, slabs, R, (int)C, rows, so);
     } else {
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_gather<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gather<T, 1>), grid, dim3(256), lds, stream, slabs, R, (int)C, rows);
+        hipLaunchKernelGGL((k_gather<T, 1>), grid, dim3(256), lds, stream, slabs, R, (int)C, rows, so);
     }
     MIQ_CHECK_LAUNCH("miq_gather_lastdim");
     return 0;

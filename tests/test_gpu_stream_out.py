@@ -100,3 +100,18 @@ def test_activation_slab_above_the_limit():
     outs, codes, vecs = F.act_fresh_quant_fwd([x], 4, layout, want_codes=True)
     ref, ref_codes, st = F.act_calib_quant_fwd(x, 4, "minmax", layout, want_codes=True)
     assert torch.equal(outs[0], ref) and torch.equal(codes[0], ref_codes) and torch.equal(vecs[0][2], st["scale"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_gather_above_the_limit(dtype):
+    """The channel gather streams its output from 16 MiB per launch on: a tensor above the limit, and a batch of two whose
+    sum is above it, equal torch's index_select."""
+    rows, C = 4608, 2048 if dtype == torch.float16 else 1024   # 18.9 MB
+    x = synth.activation((rows, C), 31, dtype).to(DEV)
+    idx = synth.permutation(C, 32).to(torch.int32).to(DEV)
+    assert x.numel() * x.element_size() >= (16 << 20)
+    assert same(F.gather_lastdim(x, idx), x.index_select(-1, idx.long()))
+    halves = [x[: rows // 2].contiguous(), x[rows // 2:].contiguous()]
+    idx2 = synth.permutation(C, 33).to(torch.int32).to(DEV)
+    outs = F.gather_lastdim_batch(halves, [idx, idx2])
+    assert same(outs[0], halves[0].index_select(-1, idx.long())) and same(outs[1], halves[1].index_select(-1, idx2.long()))
