@@ -49,7 +49,10 @@ def main():
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summary.py"), paths["fetch"], paths["write"], per_kernel],
                    check=True, stdout=subprocess.DEVNULL)
     fam = json.load(open(per_kernel))["families_total_bytes"]
-    steps = 3  # --steps 2 --warmup 1 in eager mode: every step is dispatched and counted
+    # every pass of the eager run is dispatched and counted (warm-up, the instrumented pass, the leave-one-out sequences,
+    # the timed steps); each family runs equally often, the row forward with two launches per pass
+    steps = fam["rowquant_fwd"]["dispatches"] / 2
+    assert steps == int(steps) and fam["rowquant_bwd"]["dispatches"] == 2 * steps and fam["gather"]["dispatches"] == 2 * steps, fam
     t = {"_per": "step"}
     for k in ("act_bwd", "act_calib_quant_fwd", "rowquant_bwd", "rowquant_fwd"):
         t[k] = round((fam[k]["read"] + fam[k]["write"]) / steps)
