@@ -426,7 +426,7 @@ def run_c4(args, world, rank, dev, rehearsal, barrier):
 
 
 L7 = [(o, c) for _n, o, c in WEIGHTS]
-C34_KERNEL = {"exp2": ("k_exp2_fwd_batch", "k_exp2_bwd_batch"), "exp1": ("k_exp1_fwd", "k_exp1_bwd"),
+C34_KERNEL = {"exp2": ("k_exp2_fwd_batch", "k_exp2_bwd_batch"), "exp1": ("k_exp1_fwd_batch", "k_exp1_bwd_batch"),
               "mix_soft": ("k_mix_fwd_batch", "k_mix_bwd_batch"), "mix_hard": ("k_mix_fwd_batch", "k_mix_bwd_batch"),
               "mix2": ("k_uniform_fwd_bits_batch", "k_uniform_bwd_bits_batch")}
 
@@ -492,9 +492,9 @@ def families_c3_c4(dev, replays=20, rounds=3):
            lambda: [F.rowquant_exp2_bwd_batch(sel(gs, g), sel(xs, g), 3, sel(ups, g), sel(lows, g)) for g in groups],
            nbytes, len(groups))
     record("exp1", "Llama-2-7B layer (7 matrices), W3 symmetric, fp32, LWC",
-           lambda: [F.rowquant_exp1_fwd(x, 3, True, u, l) for x, u, l in zip(xs, ups, lows)],
-           lambda: [F.rowquant_exp1_bwd(g, x, 3, True, u, l) for g, x, u, l in zip(gs, xs, ups, lows)],
-           nbytes, len(xs))
+           lambda: [F.rowquant_exp1_fwd_batch(sel(xs, g), 3, True, sel(ups, g), sel(lows, g)) for g in groups],
+           lambda: [F.rowquant_exp1_bwd_batch(sel(gs, g), sel(xs, g), 3, True, sel(ups, g), sel(lows, g)) for g in groups],
+           nbytes, len(groups))
     del xs, gs, ups, lows
     torch.cuda.empty_cache()
     # mixed-bit quantizers, the seven Llama-2-13B matrices

@@ -46,7 +46,7 @@ extern "C" {
  * raw factors and a flag bit 1 for this form; the bit is ignored now.) */
 
 /* major*10000 + minor*100 + patch of this interface; it grows when an entry point is added or a signature changes
- * (302: miq_act_static_init; 301: miq_gather_lastdim_batch; 300: up / low are the activated clip factors in every row-wise entry point; 200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
+ * (303: miq_rowquant_exp1_fwd_batch / _bwd_batch; 302: miq_act_static_init; 301: miq_gather_lastdim_batch; 300: up / low are the activated clip factors in every row-wise entry point; 200: row statistics output of miq_masked_softmax_fwd, miq_masked_softmax_bwd_scores, the *_fwd_stats norm kernels,
  * miq_act_quant_from_table, miq_gather_layernorm_bwd, miq_act_calib_quant_fwd_static) */
 int miq_version(void);
 const char* miq_last_error(void);
@@ -335,6 +335,17 @@ int miq_rowquant_exp1_fwd(const void* x, const void* up, const void* low, void* 
 int miq_rowquant_exp1_bwd(const void* grad_out, const void* x, const void* up, const void* low, void* dx,
                           void* d_up, void* d_low, int64_t O, int64_t I, int64_t group, int n_bits,
                           int symmetric, int flags, int dtype, void* stream);
+/* The same over n (1..16) matrices [O_i, I] of one row width and dtype in one launch each way (whole rows, no groups;
+ * pointer tables like miq_rowquant_exp2_fwd_batch; mid_out may be NULL when symmetric).  Results are those of the
+ * single-matrix entry points bit for bit.  No counterpart in the reference, which quantizes the weight matrices of a
+ * block one after the other (quantize/int_linear.py:72-87). */
+int miq_rowquant_exp1_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low, void* const* out,
+                                void* const* scale_out, void* const* mid_out, const int64_t* O, int64_t I, int n_bits,
+                                int symmetric, int flags, int dtype, void* stream);
+int miq_rowquant_exp1_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
+                                const int64_t* O, int64_t I, int n_bits, int symmetric, int flags, int dtype, void* stream);
+
 
 /*
  * Learnable per-row bit-width quantizer: blend of the floor(n)- and ceil(n)-bit uniform grids.

@@ -14,4 +14,4 @@ extern "C" void miq_set_error(const char* fmt, ...) {
 
 extern "C" const char* miq_last_error(void) { return g_err; }
 
-extern "C" int miq_version(void) { return 302; }  // major*10000 + minor*100 + patch
+extern "C" int miq_version(void) { return 303; }  // major*10000 + minor*100 + patch

@@ -530,14 +530,10 @@ __device__ __forceinline__ void exp1_plain_grad(float xv, float gv, const Exp1Ct
     ds = (live | (v == 0.f)) ? 0.f : gv * __builtin_copysignf(p, v);
 }
 
+// the work of one team on one quantization row
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out, T* __restrict__ mid_out) {
-    __shared__ float lds[32];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= geo.n_rows) return;
+__device__ __forceinline__ void exp1_fwd_row(const ExpArgs<T>& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                             T* __restrict__ out, T* __restrict__ scale_out, T* __restrict__ mid_out) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -580,19 +576,42 @@ k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale
     }
 }
 
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp1_fwd(ExpArgs<T> a, RowGeom geo, T* __restrict__ out, T* __restrict__ scale_out, T* __restrict__ mid_out) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    exp1_fwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, out, scale_out, mid_out);
+}
+
+// several matrices of one row width in one launch (a2 = the midpoints, or null)
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp1_fwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
+    __shared__ float lds[32];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    exp1_fwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.out[m], b.a1[m], b.a2[m]);
+}
+
 // Autograd of v1.  With P = 2^e * sign, live = [e_lo <= round(log2 mag) <= 0] & [1e-5 <= |u| <= 1e4]:
 //   du = live * (ln2 * 2^e * sign * s * g) / (mag * ln2) * sgn(u)          (through pow, round_ste, log2, clamp, abs)
 //   dv = du / s;  d_s = sum g*P + sum du * (-v / s^2);  d_mid = sum g - sum dv
 //   sym : d|max| = mask * d_s;      asym: d_range = mask * d_s / 2, d_xmax = d_range + d_mid/2, d_xmin = -d_range + d_mid/2
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
-k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
-           T* __restrict__ d_low) {
-    __shared__ float lds[64];
-    constexpr int RPB = block_of<TEAM>() / TEAM;
-    const int lane = threadIdx.x % TEAM;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
-    if (row >= geo.n_rows) return;
+__device__ __forceinline__ void exp1_bwd_row(const ExpArgs<T>& a, const RowGeom& geo, long long row, int lane, float* lds,
+                                             const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
+                                             T* __restrict__ d_low) {
     long long base;
     int len;
     row_span(geo, row, base, len);
@@ -754,6 +773,36 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     }
 }
 
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>())
+k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
+           T* __restrict__ d_low) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= geo.n_rows) return;
+    exp1_bwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, gout, dx, d_up, d_low);
+}
+
+// (fp32: four waves per SIMD, i.e. two 512-lane blocks per CU; the batch table costs the 6-pack tile 8 registers, and at
+// 130 a CU would hold a single block)
+template <typename T, int VEC, int TEAM, int NV>
+__global__ void __launch_bounds__(block_of<TEAM>(), (sizeof(T) == 4 && TEAM == 512 && NV <= 6) ? 4 : 1)
+k_exp1_bwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
+    __shared__ float lds[64];
+    constexpr int RPB = block_of<TEAM>() / TEAM;
+    const int lane = threadIdx.x % TEAM;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TEAM;
+    if (row >= b.row_start[b.n]) return;
+    long long local;
+    const int m = batch_locate(b, row, local);
+    a.x = b.x[m];
+    a.up = b.up[m];
+    a.low = b.low[m];
+    exp1_bwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.gout[m], b.out[m], b.a1[m], b.a2[m]);
+}
+
 template <typename T>
 static int launch_exp(int which, bool backward, const void* gout, const void* x, const void* up, const void* low,
                       void* out_or_dx, void* a1, void* a2, long long O, long long I, long long group, int n_bits,
@@ -790,12 +839,14 @@ static int launch_exp(int which, bool backward, const void* gout, const void* x,
     return 0;
 }
 
-// v2 over several matrices of one row width (whole rows, no groups): one launch each way
+// several matrices of one row width (whole rows, no groups): one launch each way.  a2: backward d_low; forward of v1 the
+// midpoints (may be null), unused by v2
 template <typename T>
-static int launch_exp2_batch(bool backward, int n, const void* const* gout, const void* const* x, const void* const* up,
-                             const void* const* low, void* const* out_or_dx, void* const* a1, void* const* a2, const int64_t* O,
-                             long long I, int n_bits, int flags, hipStream_t stream) {
-    const char* name = backward ? "miq_rowquant_exp2_bwd_batch" : "miq_rowquant_exp2_fwd_batch";
+static int launch_exp_batch(int which, bool backward, int n, const void* const* gout, const void* const* x, const void* const* up,
+                            const void* const* low, void* const* out_or_dx, void* const* a1, void* const* a2, const int64_t* O,
+                            long long I, int n_bits, int symmetric, int flags, hipStream_t stream) {
+    const char* name = which == 2 ? (backward ? "miq_rowquant_exp2_bwd_batch" : "miq_rowquant_exp2_fwd_batch")
+                                  : (backward ? "miq_rowquant_exp1_bwd_batch" : "miq_rowquant_exp1_fwd_batch");
     if (n == 0 || I == 0) return 0;
     MIQ_CHECK_ARG(n > 0 && n <= kMaxBatch && x && O && I > 0 && I < (1ll << 31), "%s: 1..%d matrices of one width expected", name, kMaxBatch);
     MIQ_CHECK_ARG(n_bits >= 2 && n_bits <= 4, "%s: n_bits=%d outside [2,4]", name, n_bits);
@@ -818,7 +869,7 @@ static int launch_exp2_batch(bool backward, int n, const void* const* gout, cons
         b.gout[m] = backward ? (const T*)gout[i] : nullptr;
         b.out[m] = (backward && !want_dx) ? nullptr : (T*)out_or_dx[i];
         b.a1[m] = (backward && !lwc) ? nullptr : (T*)a1[i];
-        b.a2[m] = (backward && lwc) ? (T*)a2[i] : nullptr;
+        b.a2[m] = (backward && lwc) ? (T*)a2[i] : ((!backward && which == 1 && a2) ? (T*)a2[i] : nullptr);
         MIQ_CHECK_ARG(b.x[m] && (!lwc || (b.up[m] && b.low[m])) && (!backward || b.gout[m]) && (backward || (b.out[m] && b.a1[m])) &&
                           (!want_dx || b.out[m]) && (!(backward && lwc) || (b.a1[m] && b.a2[m])),
                       "%s: null pointer in entry %d (LWC and dx must be given for all matrices or for none)", name, i);
@@ -836,7 +887,7 @@ static int launch_exp2_batch(bool backward, int n, const void* const* gout, cons
     geo.stream_out = stream_out_of(rows * I * (long long)sizeof(T));
     ExpArgs<T> a{};
     a.n_bits = n_bits;
-    a.symmetric = 1;
+    a.symmetric = which == 2 ? 1 : symmetric;
     const int npack = vec_ok ? geo.g / N : geo.g;
     MIQ_CHECK_ARG(npack <= kRowMaxPacks, "%s: row of %d elements exceeds the register tile", name, geo.g);
 #define LAUNCH_ONE(KERN, VECN, TEAM, NV)                                                                       \
@@ -845,27 +896,36 @@ static int launch_exp2_batch(bool backward, int n, const void* const* gout, cons
         const long long nb = (rows + (B / TEAM) - 1) / (B / TEAM);                                             \
         hipLaunchKernelGGL((KERN<T, VECN, TEAM, NV>), dim3((unsigned)nb), dim3(B), 0, stream, b, a, geo);      \
     }
-    if (!backward) {
-        if (vec_ok) {
-#define L(TEAM, NV) LAUNCH_ONE(k_exp2_fwd_batch, N, TEAM, NV)
-            MIQ_ROW_DISPATCH(npack, L);
-#undef L
-        } else {
-#define L(TEAM, NV) LAUNCH_ONE(k_exp2_fwd_batch, 1, TEAM, NV)
-            MIQ_ROW_DISPATCH(npack, L);
-#undef L
-        }
-    } else {
-        if (vec_ok) {
-#define L(TEAM, NV) LAUNCH_ONE(k_exp2_bwd_batch, N, TEAM, NV)
-            MIQ_ROW_DISPATCH_E(sizeof(T), npack, L);
-#undef L
-        } else {
-#define L(TEAM, NV) LAUNCH_ONE(k_exp2_bwd_batch, 1, TEAM, NV)
-            MIQ_ROW_DISPATCH_E(sizeof(T), npack, L);
-#undef L
-        }
+#define DISPATCH(KERN, TABLE_ESZ)                       \
+    if (vec_ok) {                                       \
+        MIQ_ROW_DISPATCH_E(TABLE_ESZ, npack, KERN##_V); \
+    } else {                                            \
+        MIQ_ROW_DISPATCH_E(TABLE_ESZ, npack, KERN##_S); \
     }
+#define F2_V(TEAM, NV) LAUNCH_ONE(k_exp2_fwd_batch, N, TEAM, NV)
+#define F2_S(TEAM, NV) LAUNCH_ONE(k_exp2_fwd_batch, 1, TEAM, NV)
+#define B2_V(TEAM, NV) LAUNCH_ONE(k_exp2_bwd_batch, N, TEAM, NV)
+#define B2_S(TEAM, NV) LAUNCH_ONE(k_exp2_bwd_batch, 1, TEAM, NV)
+#define F1_V(TEAM, NV) LAUNCH_ONE(k_exp1_fwd_batch, N, TEAM, NV)
+#define F1_S(TEAM, NV) LAUNCH_ONE(k_exp1_fwd_batch, 1, TEAM, NV)
+#define B1_V(TEAM, NV) LAUNCH_ONE(k_exp1_bwd_batch, N, TEAM, NV)
+#define B1_S(TEAM, NV) LAUNCH_ONE(k_exp1_bwd_batch, 1, TEAM, NV)
+    // (the forward kernels take the 4-byte tile table for every element size, the backward kernels the table of the
+    // element's own size, as the single-matrix launches do)
+    if (which == 2) {
+        if (!backward) { DISPATCH(F2, 4) } else { DISPATCH(B2, sizeof(T)) }
+    } else {
+        if (!backward) { DISPATCH(F1, 4) } else { DISPATCH(B1, sizeof(T)) }
+    }
+#undef F2_V
+#undef F2_S
+#undef B2_V
+#undef B2_S
+#undef F1_V
+#undef F1_S
+#undef B1_V
+#undef B1_S
+#undef DISPATCH
 #undef LAUNCH_ONE
     MIQ_CHECK_LAUNCH(name);
     return 0;
@@ -906,9 +966,9 @@ extern "C" int miq_rowquant_exp2_fwd_batch(int n, const void* const* x, const vo
                                            void* const* out, void* const* scale_out, const int64_t* O, int64_t I, int n_bits,
                                            int flags, int dtype, void* stream) {
     if (dtype == MIQ_F32)
-        return miq::launch_exp2_batch<float>(false, n, nullptr, x, up, low, out, scale_out, nullptr, O, I, n_bits, flags, (hipStream_t)stream);
+        return miq::launch_exp_batch<float>(2, false, n, nullptr, x, up, low, out, scale_out, nullptr, O, I, n_bits, 1, flags, (hipStream_t)stream);
     if (dtype == MIQ_F16)
-        return miq::launch_exp2_batch<__half>(false, n, nullptr, x, up, low, out, scale_out, nullptr, O, I, n_bits, flags, (hipStream_t)stream);
+        return miq::launch_exp_batch<__half>(2, false, n, nullptr, x, up, low, out, scale_out, nullptr, O, I, n_bits, 1, flags, (hipStream_t)stream);
     miq_set_error("miq_rowquant_exp2_fwd_batch: unsupported dtype %d", dtype);
     return -22;
 }
@@ -917,9 +977,32 @@ extern "C" int miq_rowquant_exp2_bwd_batch(int n, const void* const* grad_out, c
                                            const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
                                            const int64_t* O, int64_t I, int n_bits, int flags, int dtype, void* stream) {
     if (dtype == MIQ_F32)
-        return miq::launch_exp2_batch<float>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, flags, (hipStream_t)stream);
+        return miq::launch_exp_batch<float>(2, true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, 1, flags, (hipStream_t)stream);
     if (dtype == MIQ_F16)
-        return miq::launch_exp2_batch<__half>(true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, flags, (hipStream_t)stream);
+        return miq::launch_exp_batch<__half>(2, true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, 1, flags, (hipStream_t)stream);
     miq_set_error("miq_rowquant_exp2_bwd_batch: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_rowquant_exp1_fwd_batch(int n, const void* const* x, const void* const* up, const void* const* low,
+                                           void* const* out, void* const* scale_out, void* const* mid_out, const int64_t* O,
+                                           int64_t I, int n_bits, int symmetric, int flags, int dtype, void* stream) {
+    if (dtype == MIQ_F32)
+        return miq::launch_exp_batch<float>(1, false, n, nullptr, x, up, low, out, scale_out, mid_out, O, I, n_bits, symmetric, flags, (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return miq::launch_exp_batch<__half>(1, false, n, nullptr, x, up, low, out, scale_out, mid_out, O, I, n_bits, symmetric, flags, (hipStream_t)stream);
+    miq_set_error("miq_rowquant_exp1_fwd_batch: unsupported dtype %d", dtype);
+    return -22;
+}
+
+extern "C" int miq_rowquant_exp1_bwd_batch(int n, const void* const* grad_out, const void* const* x, const void* const* up,
+                                           const void* const* low, void* const* dx, void* const* d_up, void* const* d_low,
+                                           const int64_t* O, int64_t I, int n_bits, int symmetric, int flags, int dtype,
+                                           void* stream) {
+    if (dtype == MIQ_F32)
+        return miq::launch_exp_batch<float>(1, true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, symmetric, flags, (hipStream_t)stream);
+    if (dtype == MIQ_F16)
+        return miq::launch_exp_batch<__half>(1, true, n, grad_out, x, up, low, dx, d_up, d_low, O, I, n_bits, symmetric, flags, (hipStream_t)stream);
+    miq_set_error("miq_rowquant_exp1_bwd_batch: unsupported dtype %d", dtype);
     return -22;
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MIQ_LIB") or os.path.join(_HERE, "libmiq.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "miq.h"))
 
 F32, F16 = 0, 1
-MIN_VERSION = 302  # include/miq.h: what each interface version added
+MIN_VERSION = 303  # include/miq.h: what each interface version added
 _DT = {torch.float32: F32, torch.float16: F16}
 
 _lib = None

@@ -1432,6 +1432,45 @@ def rowquant_exp1_bwd(grad_out, x, n_bits: int, symmetric: bool, up=None, low=No
     return dx, d_up, d_low
 
 
+def rowquant_exp1_fwd_batch(xs, n_bits: int, symmetric: bool, ups=None, lows=None):
+    """The exponent (v1) quantizer over several [O_i, I] matrices of one width and dtype in one launch.
+    Returns (outs, scales, mids|None) lists; bit-identical to rowquant_exp1_fwd per matrix."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*xs, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows)
+    I = xs[0].shape[1]
+    outs = [torch.empty_like(x) for x in xs]
+    scales = [torch.empty((x.shape[0], 1), dtype=x.dtype, device=dev) for x in xs]
+    mids = None if symmetric else [torch.empty((x.shape[0], 1), dtype=x.dtype, device=dev) for x in xs]
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with L.on_device(dev):
+        L.call("miq_rowquant_exp1_fwd_batch", L.i32(len(xs)), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(outs), _ptr_table(scales), _ptr_table(mids) if mids else None, O,
+               L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))), L.i32(_flags(False)), L.i32(L.dtype_code(xs[0])),
+               L.stream_of(xs[0]))
+    return outs, scales, mids
+
+
+def rowquant_exp1_bwd_batch(gs, xs, n_bits: int, symmetric: bool, ups=None, lows=None, want_dx: bool = True):
+    """Backward of the above.  Returns (dxs|None, d_ups|None, d_lows|None) lists."""
+    import ctypes
+    lwc = ups is not None
+    dev = L.check_gpu(*gs, *xs, *(ups or []), *(lows or []))
+    _check_batch(xs, ups, lows, gs)
+    I = xs[0].shape[1]
+    dxs = [torch.empty_like(x) for x in xs] if want_dx else None
+    d_ups = [torch.empty_like(u) for u in ups] if lwc else None
+    d_lows = [torch.empty_like(u) for u in lows] if lwc else None
+    O = (ctypes.c_int64 * len(xs))(*[x.shape[0] for x in xs])
+    with L.on_device(dev):
+        L.call("miq_rowquant_exp1_bwd_batch", L.i32(len(xs)), _ptr_table(gs), _ptr_table(xs), _ptr_table(ups) if lwc else None,
+               _ptr_table(lows) if lwc else None, _ptr_table(dxs) if want_dx else None, _ptr_table(d_ups) if lwc else None,
+               _ptr_table(d_lows) if lwc else None, O, L.i64(I), L.i32(int(n_bits)), L.i32(int(bool(symmetric))),
+               L.i32(_flags(False)), L.i32(L.dtype_code(xs[0])), L.stream_of(xs[0]))
+    return dxs, d_ups, d_lows
+
+
 def rowquant_mix_fwd(x, n_bits_rows, symmetric: bool, up=None, low=None, group: int = 0, hard=False, threshold=0.0):
     dev = L.check_gpu(x, up, low, n_bits_rows)
     if x.dtype != torch.float32 or n_bits_rows.dtype != torch.float32:

@@ -125,6 +125,42 @@ def test_exp2_batch_equals_single_matrix_calls(dt, lwc):
         F.rowquant_exp2_fwd_batch([xs[0], xs[1][:, :512].contiguous()], 3)
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("lwc", [True, False])
+@pytest.mark.parametrize("sym", [True, False])
+def test_exp1_batch_equals_single_matrix_calls(dt, lwc, sym):
+    """The exponent (v1) quantizer over several matrices of one width in one launch each way: the bits of the
+    single-matrix entry points (output, scale, midpoint; dx and the clip-factor gradients), symmetric and around the
+    row midpoint, with and without clipping factors and dx, on a narrow and on a wide (two-wave team) tile."""
+    dtype = DT[dt]
+    for I, rows in ((1024, [64, 1, 130, 257]), (11008, [3, 40])):
+        xs = [synth.weight(o, I, 170 + i, dtype).to(DEV) for i, o in enumerate(rows)]
+        gs = [synth.grad_like(x.cpu(), 180 + i).to(DEV) for i, x in enumerate(xs)]
+        ups = lows = None
+        if lwc:
+            fac = [synth.lwc_clips(o, 190 + i, dtype) for i, o in enumerate(rows)]
+            ups, lows = [f[0].to(DEV) for f in fac], [f[1].to(DEV) for f in fac]
+        outs, scales, mids = F.rowquant_exp1_fwd_batch(xs, 3, sym, ups, lows)
+        assert (mids is None) == sym
+        for want_dx in (True, False):
+            dxs, d_ups, d_lows = F.rowquant_exp1_bwd_batch(gs, xs, 3, sym, ups, lows, want_dx=want_dx)
+            for i, x in enumerate(xs):
+                u, l = (ups[i], lows[i]) if lwc else (None, None)
+                o1, s1, m1 = F.rowquant_exp1_fwd(x, 3, sym, u, l)
+                assert same(outs[i].cpu(), o1.cpu()) and same(scales[i].cpu(), s1.cpu())
+                if not sym:
+                    assert same(mids[i].cpu(), m1.cpu())
+                dx1, du1, dl1 = F.rowquant_exp1_bwd(gs[i], x, 3, sym, u, l, want_dx=want_dx)
+                if want_dx:
+                    assert same(dxs[i].cpu(), dx1.cpu())
+                else:
+                    assert dxs is None
+                if lwc:
+                    assert same(d_ups[i].cpu(), du1.cpu()) and same(d_lows[i].cpu(), dl1.cpu())
+    with pytest.raises(L.MiqError):
+        F.rowquant_exp1_fwd_batch([xs[0], xs[1][:, :512].contiguous()], 3, sym)
+
+
 def test_block_with_batched_exponent_weights_trains_like_one_launch_per_matrix():
     """An OPT-125m shaped block with the exponent (v2) weight quantizer: the calibration step that quantizes the
     weight matrices of one width in one launch each way ends at the same parameters, bit for bit, as the step that
