@@ -219,6 +219,19 @@ k_exp2_fwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
     exp2_fwd_row<T, VEC, TEAM, NV>(a, geo, local, lane, lds, b.out[m], b.a1[m]);
 }
 
+// Minimum waves per SIMD asked of the backward kernels (fp32): the 512-lane tiles of 6 and 7 packs must stay inside 128
+// registers (two blocks per CU; at 130 to 154 registers a CU holds ONE 512-lane block), the 256 x 4 tile of v2 inside 96
+// (five waves per SIMD instead of four).
+template <typename T, int TEAM, int NV, int WHICH>
+constexpr int exp_bwd_waves() {
+    if (sizeof(T) != 4) return 1;
+    if (TEAM == 512 && (NV == 6 || NV == 7)) return 4;
+    // (v2: 99 -> 96 registers with 20 bytes of spills, backward 0.69 -> 0.71 of peak on the Llama-2-7B layer; v1 would
+    // spill 52 bytes and lose: 0.68 -> 0.61)
+    if (WHICH == 2 && TEAM == 256 && NV == 4) return 5;
+    return 1;
+}
+
 // Reference backward (quantizer_exp_v2.py:65-105), element by element:
 //   gq   = g*s, negated where sign == -1; zeroed where the level saturates, is the zero bin, or
 //          the threshold branch was taken;  grad_q = ((ln2*lvl)*gq / ln2 / mag) * sign
@@ -384,7 +397,7 @@ __device__ __forceinline__ void exp2_bwd_row(const ExpArgs<T>& a, const RowGeom&
 }
 
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
+__global__ void __launch_bounds__(block_of<TEAM>(), (exp_bwd_waves<T, TEAM, NV, 2>()))
 k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
            T* __restrict__ d_low) {
     __shared__ float lds[64];
@@ -396,7 +409,7 @@ k_exp2_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
 }
 
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
+__global__ void __launch_bounds__(block_of<TEAM>(), (exp_bwd_waves<T, TEAM, NV, 2>()))
 k_exp2_bwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
     __shared__ float lds[64];
     constexpr int RPB = block_of<TEAM>() / TEAM;
@@ -774,7 +787,7 @@ __device__ __forceinline__ void exp1_bwd_row(const ExpArgs<T>& a, const RowGeom&
 }
 
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>())
+__global__ void __launch_bounds__(block_of<TEAM>(), (exp_bwd_waves<T, TEAM, NV, 1>()))
 k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict__ dx, T* __restrict__ d_up,
            T* __restrict__ d_low) {
     __shared__ float lds[64];
@@ -785,10 +798,8 @@ k_exp1_bwd(ExpArgs<T> a, RowGeom geo, const T* __restrict__ gout, T* __restrict_
     exp1_bwd_row<T, VEC, TEAM, NV>(a, geo, row, lane, lds, gout, dx, d_up, d_low);
 }
 
-// (fp32: four waves per SIMD, i.e. two 512-lane blocks per CU; the batch table costs the 6-pack tile 8 registers, and at
-// 130 a CU would hold a single block)
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>(), (sizeof(T) == 4 && TEAM == 512 && NV <= 6) ? 4 : 1)
+__global__ void __launch_bounds__(block_of<TEAM>(), (exp_bwd_waves<T, TEAM, NV, 1>()))
 k_exp1_bwd_batch(UniBatch<T> b, ExpArgs<T> a, RowGeom geo) {
     __shared__ float lds[64];
     constexpr int RPB = block_of<TEAM>() / TEAM;

@@ -323,7 +323,7 @@ __device__ __forceinline__ void mix_bwd_row(const MixArgs& a, const RowGeom& geo
 }
 
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>(), (TEAM == 512 && NV == 6) ? 4 : 1)  // the 6-pack tile stays inside 128 registers
+__global__ void __launch_bounds__(block_of<TEAM>(), (TEAM == 512 && (NV == 6 || NV == 7)) ? 4 : 1)  // the 6- and 7-pack tiles stay inside 128 registers
 k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restrict__ dx, float* __restrict__ d_up,
           float* __restrict__ d_low, float* __restrict__ d_nbits) {
     __shared__ float lds[96];
@@ -335,7 +335,7 @@ k_mix_bwd(MixArgs a, RowGeom geo, const float* __restrict__ gout, float* __restr
 }
 
 template <typename T, int VEC, int TEAM, int NV>
-__global__ void __launch_bounds__(block_of<TEAM>(), (TEAM == 512 && NV == 6) ? 4 : 1)  // the 6-pack tile stays inside 128 registers
+__global__ void __launch_bounds__(block_of<TEAM>(), (TEAM == 512 && (NV == 6 || NV == 7)) ? 4 : 1)  // the 6- and 7-pack tiles stay inside 128 registers
 k_mix_bwd_batch(UniBatch<float> b, MixBatchBits nb, MixArgs a, RowGeom geo) {
     __shared__ float lds[96];
     constexpr int RPB = block_of<TEAM>() / TEAM;
