@@ -7,7 +7,8 @@
   C4  Llama-2-13B mixed bit        learnable mixed-bit (soft and hard) and fixed mixed-bit on the seven 13B shapes
 
 Every kernel sequence of a configuration is captured in one HIP graph over rotating buffer sets that together
-exceed the 256 MiB Infinity Cache, and the graph is timed with HIP events (median of 7 replays).  Algorithmic
+exceed the 256 MiB Infinity Cache, and the graph is timed with HIP events (10 back-to-back replays between one pair
+of events, median of three rounds).  Algorithmic
 bytes: forward 2ns, backward 3ns (2ns without dx), calibrate+quantize 3ns, gather 2ns.
 Prints one JSON object; --out writes it to a file.
 """
@@ -28,7 +29,7 @@ L7 = [(4096, 4096)] * 4 + [(11008, 4096)] * 2 + [(4096, 11008)]
 L13 = [(5120, 5120)] * 4 + [(13824, 5120)] * 2 + [(5120, 13824)]
 
 
-def time_graph(fn, reps=7):
+def time_graph(fn, reps=10, rounds=3):
     # warm up ON the capture stream: per-stream state of the library (the activation kernels' statistics table) must
     # exist before the capture, which refuses to allocate it
     side = torch.cuda.Stream()
@@ -42,13 +43,14 @@ def time_graph(fn, reps=7):
     g.replay()
     torch.cuda.synchronize()
     ts = []
-    for _ in range(reps):
+    for _ in range(rounds):  # an event record costs about 5 us of stream time: `reps` replays share one pair (as in bench.py)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        g.replay()
+        for _ in range(reps):
+            g.replay()
         b.record()
         torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b) * 1e-3)
+        ts.append(a.elapsed_time(b) * 1e-3 / reps)
     return sorted(ts)[len(ts) // 2]
 
 
