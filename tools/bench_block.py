@@ -67,7 +67,7 @@ def synthetic_block(model, dev, args, seed=2):
 
 
 def run(model="7b", samples=4, epochs=2, amp=False, act="per_tensor", wbits=4, abits=4, seq=2048, dev="cuda:0",
-        dp: DPContext | None = None, let=None, wexp=False, wsym=False, warmup=True, reference_s_per_layer=None, graph=False):
+        dp: DPContext | None = None, let=None, wexp=False, wsym=False, warmup=True, reference_s_per_layer=None, graph=False, fused_adamw=False):
     """Returns a dict of timings.  ``samples`` is the number of samples THIS rank holds."""
     dp = dp or DPContext()
     H, FF, heads, kv = SHAPES[model]
@@ -77,7 +77,7 @@ def run(model="7b", samples=4, epochs=2, amp=False, act="per_tensor", wbits=4, a
     args = quant_args(wbits=wbits, abits=abits, lwc=True, a_dynamic_method=act, a_dynamic=(act == "per_token"),
                       metric="ema_minmax", let=let, weight_exp_quant=wexp, w_symmetric=wsym)
     if warmup:  # first-use costs (library handles, GEMM heuristics, allocator growth) stay out of the timing
-        run(model, 2, 1, amp, act, wbits, abits, seq, dev, dp, let, wexp, wsym, warmup=False, graph=graph)
+        run(model, 2, 1, amp, act, wbits, abits, seq, dev, dp, let, wexp, wsym, warmup=False, graph=graph, fused_adamw=fused_adamw)
     qlayer, _ = synthetic_block(model, dev, args)
     g = torch.Generator(device=dev).manual_seed(100 + dp.rank)
     dtype = torch.float16 if amp else torch.float32
@@ -85,7 +85,7 @@ def run(model="7b", samples=4, epochs=2, amp=False, act="per_tensor", wbits=4, a
     fp = inps.clone()
     mask = torch.full((seq, seq), torch.finfo(dtype).min, device=dev, dtype=dtype).triu(1).view(1, 1, seq, seq)
     cfg = CalibConfig(epochs=epochs, nsamples=samples * dp.world, batch_size=1, let=let, lwc=True, deactive_amp=not amp,
-                      reorder="", graph_step=graph)
+                      reorder="", graph_step=graph, fused_adamw=fused_adamw)
     prefix = "model.layers.0" if is_llama else "model.decoder.layers.0"
     sites = ("self_attn.q_proj", "self_attn.o_proj", "mlp.up_proj") if is_llama else ("self_attn.q_proj", "self_attn.out_proj", "fc1")
     act_scales = {f"{prefix}.{n}": torch.rand(H, generator=g, device=dev) * 3 + 0.2 for n in sites}
@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--amp", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward + loss + backward of a step from one HIP graph")
+    ap.add_argument("--fused-adamw", action="store_true",
+                    help="torch's fused AdamW (no host synchronisation in GradScaler.step; its update differs in the last bits, "
+                         "which moves the trajectory: not the reference's arithmetic)")
     ap.add_argument("--act", default="per_tensor", choices=["per_tensor", "per_cluster", "per_token"])
     ap.add_argument("--abits", type=int, default=4)
     ap.add_argument("--wbits", type=int, default=4)
@@ -144,10 +147,10 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         dp = DPContext.from_env()
     if a.reference_log:
-        out = run(seq=a.seq, dev=f"cuda:{local}", dp=dp, graph=a.graph, **REFERENCE_LOG)
+        out = run(seq=a.seq, dev=f"cuda:{local}", dp=dp, graph=a.graph, fused_adamw=a.fused_adamw, **REFERENCE_LOG)
     else:
         out = run(a.model, a.samples, a.epochs, a.amp, a.act, a.wbits, a.abits, a.seq, f"cuda:{local}", dp, wexp=a.wexp,
-                  wsym=a.wsym, graph=a.graph)
+                  wsym=a.wsym, graph=a.graph, fused_adamw=a.fused_adamw)
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(out))
     if world > 1:
